@@ -1,0 +1,156 @@
+"""
+ctypes binding of libaliby_hip.so (include/aliby_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or
+creating a context without a visible MI355X, raises.  `oracle/` is never
+imported from here.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libaliby_hip.so"
+
+OK, ERR_INVALID, ERR_OVERFLOW, ERR_HIP, ERR_TOO_LARGE, ERR_UNSUPPORTED = range(6)
+U16, F32 = 0, 1
+RED_MAX, RED_ADD, RED_DIV = 0, 1, 2
+
+
+class AlibyHipError(RuntimeError):
+    pass
+
+
+class aliby_object(C.Structure):
+    _fields_ = [
+        ("tile", C.c_int32),
+        ("label", C.c_int32),
+        ("y0", C.c_int32),
+        ("x0", C.c_int32),
+        ("y1", C.c_int32),
+        ("x1", C.c_int32),
+        ("area", C.c_int32),
+        ("pad_", C.c_int32),
+    ]
+
+
+OBJECT_DTYPE = np.dtype(
+    [("tile", "<i4"), ("label", "<i4"), ("y0", "<i4"), ("x0", "<i4"), ("y1", "<i4"), ("x1", "<i4"),
+     ("area", "<i4"), ("pad_", "<i4")]
+)
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_ip = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); mirrors include/aliby_hip.h one to one
+_SIGNATURES = {
+    "aliby_abi_version": (_i, []),
+    "aliby_last_error": (C.c_char_p, []),
+    "aliby_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "aliby_ctx_destroy": (_i, [_vp]),
+    "aliby_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz), C.c_char_p, _i]),
+    "aliby_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "aliby_free": (_i, [_vp, _vp]),
+    "aliby_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "aliby_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "aliby_memset": (_i, [_vp, _vp, _i, _sz, _vp]),
+    "aliby_stream_sync": (_i, [_vp, _vp]),
+    "aliby_label_max": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_object_table": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "aliby_relabel_sequential": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_features_intensity": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "aliby_features_sizeshape": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGNATURES)
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  torch is imported first so that its
+    bundled HIP runtime (same SONAME, libamdhip64.so.7) is the one both share."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise AlibyHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C aliby_amd/csrc). There is no CPU fallback for the HIP path."
+        )
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 before our DT_NEEDED resolves)
+    except Exception:  # pragma: no cover - torch is part of the image
+        pass
+    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aliby_abi_version() != 1:
+        raise AlibyHipError("libaliby_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Map C status codes to the exception types the reference raises."""
+    if rc == OK:
+        return
+    msg = load().aliby_last_error().decode("utf-8", "replace")
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_OVERFLOW:
+        raise OverflowError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise Exception(msg)
+    raise AlibyHipError(msg)
+
+
+class Context:
+    """Owns an aliby_ctx*; one per process/GPU (one process per GPU, SURVEY §8b "Threading")."""
+
+    def __init__(self, device: int = 0):
+        lib = load()
+        h = _vp()
+        check(lib.aliby_ctx_create(device, C.byref(h)))
+        self.handle = h
+        self.lib = lib
+        self.device = device
+
+    def info(self) -> dict:
+        cu, lds, hbm = _i(), _i(), _sz()
+        name = C.create_string_buffer(128)
+        check(self.lib.aliby_device_info(self.handle, C.byref(cu), C.byref(lds), C.byref(hbm), name, 128))
+        return dict(cu_count=cu.value, lds_bytes=lds.value, hbm_bytes=hbm.value, name=name.value.decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.aliby_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        import torch
+
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

@@ -1,0 +1,159 @@
+// common.h — shared host/device helpers for libaliby_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/aliby_hip.h"
+
+#define WAVE 64
+
+struct aliby_ctx {
+  int device;
+  int cu_count;
+  int lds_bytes;
+  size_t hbm_bytes;
+  char name[128];
+  // small device scratch owned by the context (per-tile counters etc.)
+  void* scratch;
+  size_t scratch_bytes;
+};
+
+void aliby_set_error(const char* fmt, ...);
+int aliby_ensure_scratch(aliby_ctx* ctx, size_t bytes);
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e__ = (expr);                                                       \
+    if (e__ != hipSuccess) {                                                       \
+      aliby_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),      \
+                      __FILE__, __LINE__);                                         \
+      return ALIBY_ERR_HIP;                                                        \
+    }                                                                              \
+  } while (0)
+
+#define ARG_CHECK(cond, msg)                                  \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      aliby_set_error("invalid argument: %s (%s)", msg, #cond); \
+      return ALIBY_ERR_INVALID;                               \
+    }                                                         \
+  } while (0)
+
+#define KERNEL_CHECK()                                                         \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      aliby_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), \
+                      __FILE__, __LINE__);                                     \
+      return ALIBY_ERR_HIP;                                                    \
+    }                                                                          \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+template <typename T>
+__device__ __forceinline__ float px_load(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float px_load<uint16_t>(const uint16_t* p, size_t i) { return (float)p[i]; }
+template <>
+__device__ __forceinline__ float px_load<float>(const float* p, size_t i) { return p[i]; }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, WAVE));
+  return v;
+}
+
+// Block-wide reductions.  `red` is an LDS array of >= blockDim.x/64 elements of T.
+// Deterministic: fixed tree inside the wave, then wave 0 folds the per-wave partials
+// in wave order.  Result is broadcast to every thread.
+#define DEFINE_BLOCK_REDUCE(NAME, T, WOP, IDENT, COMBINE)                     \
+  __device__ __forceinline__ T NAME(T v, T* red) {                            \
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;      \
+    const int nw = (blockDim.x + WAVE - 1) / WAVE;                            \
+    v = WOP(v);                                                               \
+    __syncthreads();                                                          \
+    if (lane == 0) red[wid] = v;                                              \
+    __syncthreads();                                                          \
+    T r = IDENT;                                                              \
+    for (int i = 0; i < nw; ++i) { T o = red[i]; r = COMBINE; }               \
+    return r;                                                                 \
+  }
+DEFINE_BLOCK_REDUCE(block_sum_f64, double, wave_sum, 0.0, r + o)
+DEFINE_BLOCK_REDUCE(block_sum_i64, long long, wave_sum, 0LL, r + o)
+DEFINE_BLOCK_REDUCE(block_sum_i32, int, wave_sum, 0, r + o)
+DEFINE_BLOCK_REDUCE(block_min_f32, float, wave_min, INFINITY, fminf(r, o))
+DEFINE_BLOCK_REDUCE(block_max_f32, float, wave_max, -INFINITY, fmaxf(r, o))
+DEFINE_BLOCK_REDUCE(block_max_f64, double, wave_max, -INFINITY, fmax(r, o))
+DEFINE_BLOCK_REDUCE(block_max_i32, int, wave_max, INT_MIN, max(r, o))
+DEFINE_BLOCK_REDUCE(block_min_i32, int, wave_min, INT_MAX, min(r, o))
+
+// Ascending bitonic sort of `n2` (power of two) floats; works on LDS or global
+// scratch.  All threads of the block must call it.
+template <typename T>
+__device__ __forceinline__ void block_bitonic_sort(T* a, int n2) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        int p = i ^ j;
+        if (p > i) {
+          T x = a[i], y = a[p];
+          bool up = ((i & k) == 0);
+          if ((x > y) == up) { a[i] = y; a[p] = x; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int next_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,141 @@
+"""
+Device-side feature engine: thin Python host over the C ABI (include/aliby_hip.h).
+
+torch is used for device buffers and the stream only; every computation is a
+HIP kernel in libaliby_hip.so reached through ctypes.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from aliby_amd import _lib
+from aliby_amd.extraction import features as feat
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t) -> int:
+    if t is None:
+        return 0
+    if isinstance(t, torch.Tensor):
+        return t.data_ptr()
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    raise TypeError(type(t))
+
+
+def to_device_u16(a) -> torch.Tensor:
+    """Host or device array -> contiguous uint16 tensor on the current GPU."""
+    if isinstance(a, torch.Tensor):
+        t = a
+        if t.dtype == torch.int16:
+            t = t.view(torch.uint16)
+        if t.dtype != torch.uint16:
+            raise TypeError(f"expected uint16 labels, got {t.dtype}")
+        return t.cuda().contiguous()
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint16:
+        if a.size and (a.min() < 0 or a.max() >= 65535):
+            raise OverflowError(f"labels outside uint16 range: max={a.max()}")
+        a = a.astype(np.uint16)
+    return torch.from_numpy(a).cuda()
+
+
+def to_device_planes(a) -> tuple[torch.Tensor, int]:
+    """Pixels -> (tensor, dtype code).  <=16-bit unsigned ints stay uint16; everything else is f32."""
+    if isinstance(a, torch.Tensor):
+        if a.dtype == torch.uint16:
+            return a.cuda().contiguous(), _lib.U16
+        if a.dtype == torch.uint8:
+            return a.cuda().to(torch.int32).to(torch.uint16).contiguous(), _lib.U16
+        return a.cuda().to(torch.float32).contiguous(), _lib.F32
+    a = np.asarray(a)
+    if a.dtype in (np.uint16, np.uint8, np.bool_):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint16)).cuda(), _lib.U16
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda(), _lib.F32
+
+
+@dataclass
+class ObjectTable:
+    """Compact (tile, label) table — stands in for transform_2d_to_3d's (N,Y,X) bool stack."""
+
+    dev: torch.Tensor          # uint8 [n_obj * 32] holding aliby_object rows
+    host: np.ndarray           # structured array, dtype _lib.OBJECT_DTYPE
+    offsets: np.ndarray        # int32 [F+1]
+    n_obj: int
+    max_area: int
+    max_h: int
+    max_w: int
+
+
+class FeatureEngine:
+    def __init__(self, device: int | None = None):
+        if not torch.cuda.is_available():
+            raise _lib.AlibyHipError("no GPU visible: the HIP feature engine has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = device
+        self.ctx = _lib.default_context(device)
+        self.lib = self.ctx.lib
+
+    # ------------------------------------------------------------------ objects
+    def object_table(self, labels: torch.Tensor) -> ObjectTable:
+        F, Y, X = labels.shape
+        lib, h = self.lib, self.ctx.handle
+        mx = np.zeros(F, np.int32)
+        _lib.check(lib.aliby_label_max(h, _ptr(labels), F, Y, X, _ptr(mx), _stream_ptr()))
+        offsets = np.zeros(F + 1, np.int32)
+        np.cumsum(mx, out=offsets[1:])
+        n_obj = int(offsets[-1])
+        host = np.zeros(n_obj, _lib.OBJECT_DTYPE)
+        dev = torch.empty(max(n_obj, 1) * 32, dtype=torch.uint8, device=labels.device)
+        if n_obj:
+            _lib.check(
+                lib.aliby_object_table(h, _ptr(labels), F, Y, X, _ptr(offsets), _ptr(dev), _ptr(host), _stream_ptr())
+            )
+        present = host["area"] > 0
+        if present.any():
+            hh = (host["y1"] - host["y0"])[present]
+            ww = (host["x1"] - host["x0"])[present]
+            max_area, max_h, max_w = int(host["area"].max()), int(hh.max()), int(ww.max())
+        else:
+            max_area = max_h = max_w = 0
+        return ObjectTable(dev, host, offsets, n_obj, max_area, max_h, max_w)
+
+    def relabel_sequential(self, labels: torch.Tensor) -> np.ndarray:
+        F, Y, X = labels.shape
+        n = np.zeros(F, np.int32)
+        _lib.check(self.lib.aliby_relabel_sequential(self.ctx.handle, _ptr(labels), F, Y, X, _ptr(n), _stream_ptr()))
+        return n
+
+    # ----------------------------------------------------------------- features
+    def new_output(self, n_obj: int, n_cols: int) -> torch.Tensor:
+        return torch.full((max(n_obj, 1), max(n_cols, 1)), float("nan"), dtype=torch.float64, device=f"cuda:{self.device}")[:n_obj]
+
+    def intensity(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, edge_measurements=True):
+        F, Cn, Y, X = planes.shape
+        _lib.check(
+            self.lib.aliby_features_intensity(
+                self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel), _ptr(table.dev),
+                table.n_obj, table.max_area, 1 if edge_measurements else 0, _ptr(out), out.stride(0), col0,
+                _stream_ptr(),
+            )
+        )
+        return len(feat.intensity_names(edge_measurements))
+
+    def sizeshape(self, labels, table: ObjectTable, out, col0):
+        F, Y, X = labels.shape
+        _lib.check(
+            self.lib.aliby_features_sizeshape(
+                self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj, table.max_h, table.max_w,
+                table.max_area, _ptr(out), out.stride(0), col0, _stream_ptr(),
+            )
+        )
+        return 78

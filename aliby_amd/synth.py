@@ -1,0 +1,163 @@
+"""
+Deterministic synthetic TCZYX stacks + ground-truth label images.
+
+Nothing here comes from the reference: it is the build's own generator, shared
+by tests, the oracle's CPU baseline and bench.py so that every leg sees the
+same bytes.
+
+Recipe (per field of view, `seed = 20260821 + 1000*config + fov`, PCG64):
+  * nuclei  = non-overlapping ellipses on a jittered grid, semi-axes U[8,16] px;
+  * cells   = nucleus dilated by U[6,14] px, clipped by nearest-seed Voronoi;
+  * pixels  = uint16: background 400 + N(0,30^2); per-object signal
+              A*(1-r^2)^0.5 with A~U[2000,20000] per channel, plus correlated
+              texture (Gaussian-filtered noise sigma=2, amplitude 0.15 A) and
+              Poisson shot noise; clipped to [0, 65535].
+  * analytic flows for the segmentation leg: unit vectors towards each
+    object's centre, cellprob = +6 inside / -6 outside.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy import ndimage
+
+BASE_SEED = 20260821
+
+
+def fov_seed(config: int, fov: int) -> int:
+    return BASE_SEED + 1000 * config + fov
+
+
+def _grid_centres(rng, shape, n_target, margin):
+    """Jittered-grid seeds; pitch chosen so that ~n_target cells fit."""
+    Y, X = shape
+    pitch = max(int(np.sqrt(Y * X / max(n_target, 1))), 2 * margin + 2)
+    ys = np.arange(pitch // 2, Y - margin, pitch)
+    xs = np.arange(pitch // 2, X - margin, pitch)
+    cy, cx = np.meshgrid(ys, xs, indexing="ij")
+    cy = cy.ravel().astype(np.float64)
+    cx = cx.ravel().astype(np.float64)
+    jit = max((pitch - 2 * margin) / 2.0 - 1.0, 0.0)
+    cy += rng.uniform(-jit, jit, cy.size)
+    cx += rng.uniform(-jit, jit, cx.size)
+    keep = (cy > margin) & (cy < Y - margin) & (cx > margin) & (cx < X - margin)
+    return cy[keep], cx[keep], pitch
+
+
+def make_labels(rng, shape, n_target, with_cells=True):
+    """Return (nuclei u16 [Y,X], cells u16 [Y,X], params dict)."""
+    Y, X = shape
+    cy, cx, pitch = _grid_centres(rng, shape, n_target, margin=17)
+    n = cy.size
+    # keep ellipses inside their grid cell so they never overlap
+    rmax = min(16.0, pitch / 2.0 - 1.5)
+    rmin = min(8.0, rmax)
+    a = rng.uniform(rmin, rmax, n)
+    b = rng.uniform(rmin, rmax, n)
+    th = rng.uniform(0, np.pi, n)
+    grow = rng.uniform(6.0, 14.0, n)
+    nuclei = np.zeros(shape, np.uint16)
+    yy, xx = np.mgrid[0:Y, 0:X]
+    for i in range(n):
+        r = int(np.ceil(max(a[i], b[i]))) + 1
+        y0, y1 = max(int(cy[i]) - r, 0), min(int(cy[i]) + r + 2, Y)
+        x0, x1 = max(int(cx[i]) - r, 0), min(int(cx[i]) + r + 2, X)
+        dy = yy[y0:y1, x0:x1] - cy[i]
+        dx = xx[y0:y1, x0:x1] - cx[i]
+        u = (dx * np.cos(th[i]) + dy * np.sin(th[i])) / a[i]
+        v = (-dx * np.sin(th[i]) + dy * np.cos(th[i])) / b[i]
+        m = (u * u + v * v) <= 1.0
+        sub = nuclei[y0:y1, x0:x1]
+        sub[m & (sub == 0)] = i + 1
+    cells = None
+    if with_cells:
+        # distance to every nucleus + index of the nearest one (Voronoi clip)
+        dist, (iy, ix) = ndimage.distance_transform_edt(nuclei == 0, return_indices=True)
+        nearest = nuclei[iy, ix]
+        lim = np.zeros(n + 1)
+        lim[1:] = grow
+        cells = np.where(dist <= lim[nearest], nearest, 0).astype(np.uint16)
+    params = dict(cy=cy, cx=cx, a=a, b=b, theta=th, grow=grow)
+    return nuclei, cells, params
+
+
+def make_pixels(rng, labels, params, n_channels, n_z=1):
+    """uint16 [C,Z,Y,X] rendered from `labels` (the larger object set)."""
+    Y, X = labels.shape
+    n = int(labels.max())
+    out = np.empty((n_channels, n_z, Y, X), np.uint16)
+    yy, xx = np.mgrid[0:Y, 0:X]
+    cy = np.concatenate([[0.0], params["cy"]])
+    cx = np.concatenate([[0.0], params["cx"]])
+    # normalised radius inside each object (0 at centre, ~1 at the rim)
+    dist_in = ndimage.distance_transform_edt(labels > 0)
+    rmax = np.maximum(ndimage.maximum(dist_in, labels, np.arange(n + 1)), 1.0)
+    r2 = np.clip(1.0 - dist_in / rmax[labels], 0.0, 1.0) ** 2
+    del cy, cx, yy, xx
+    inside = labels > 0
+    for c in range(n_channels):
+        amp = np.zeros(n + 1)
+        amp[1:] = rng.uniform(2000.0, 20000.0, n)
+        A = amp[labels]
+        tex = ndimage.gaussian_filter(rng.standard_normal((Y, X)), 2.0)
+        tex /= max(tex.std(), 1e-9)
+        for z in range(n_z):
+            zfall = 1.0 - 0.15 * abs(z - (n_z - 1) / 2.0)
+            sig = A * zfall * (np.sqrt(np.clip(1.0 - r2, 0.0, 1.0)) + 0.15 * tex) * inside
+            sig = np.clip(sig, 0.0, None)
+            img = 400.0 + rng.normal(0.0, 30.0, (Y, X)) + rng.poisson(sig)
+            out[c, z] = np.clip(np.rint(img), 0, 65535).astype(np.uint16)
+    return out
+
+
+def analytic_flows(labels):
+    """(dP f32 [2,Y,X] (dy,dx), cellprob f32 [Y,X]) pointing at each object's centre of mass."""
+    n = int(labels.max())
+    Y, X = labels.shape
+    dP = np.zeros((2, Y, X), np.float32)
+    prob = np.full((Y, X), -6.0, np.float32)
+    if n == 0:
+        return dP, prob
+    idx = np.arange(1, n + 1)
+    com = np.array(ndimage.center_of_mass(labels > 0, labels, idx)).reshape(n, 2)
+    cy = np.concatenate([[0.0], com[:, 0]])
+    cx = np.concatenate([[0.0], com[:, 1]])
+    yy, xx = np.mgrid[0:Y, 0:X]
+    inside = labels > 0
+    dy = (cy[labels] - yy) * inside
+    dx = (cx[labels] - xx) * inside
+    nrm = np.sqrt(dy * dy + dx * dx)
+    nrm[nrm < 1e-6] = 1.0
+    # cellpose flows have magnitude <~1 far from the centre and vanish at the centre
+    mag = np.clip(np.sqrt(dy * dy + dx * dx) / 3.0, 0.0, 1.0)
+    dP[0] = (dy / nrm * mag).astype(np.float32)
+    dP[1] = (dx / nrm * mag).astype(np.float32)
+    prob[inside] = 6.0
+    return dP, prob
+
+
+CONFIGS = {
+    # id: (n_fov, C, Z, Y, X, n_target, segment_channel)
+    1: dict(n_fov=1, C=2, Z=1, Y=512, X=512, n_target=60, seg_channel=1),
+    2: dict(n_fov=256, C=5, Z=1, Y=1024, X=1024, n_target=250, seg_channel=0),
+    3: dict(n_fov=2048, C=5, Z=1, Y=1024, X=1024, n_target=250, seg_channel=0),
+    4: dict(n_fov=1, C=1, Z=5, Y=512, X=512, n_target=60, seg_channel=0, T=200),
+    5: dict(n_fov=1, C=2, Z=32, Y=512, X=512, n_target=100, seg_channel=0),
+}
+
+
+def make_fov(config: int, fov: int = 0, shape=None, n_channels=None, n_z=None, n_target=None):
+    """One synthetic field of view.
+
+    Returns dict(pixels u16 [C,Z,Y,X], nuclei u16 [Y,X], cells u16 [Y,X], params).
+    Keyword overrides shrink the case for unit tests while keeping the seed rule.
+    """
+    cfg = CONFIGS[config]
+    shape = shape or (cfg["Y"], cfg["X"])
+    C = n_channels or cfg["C"]
+    Z = n_z or cfg["Z"]
+    nt = n_target or cfg["n_target"]
+    rng = np.random.default_rng(fov_seed(config, fov))
+    nuclei, cells, params = make_labels(rng, shape, nt)
+    pixels = make_pixels(rng, cells, params, C, Z)
+    return dict(pixels=pixels, nuclei=nuclei, cells=cells, params=params)

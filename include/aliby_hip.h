@@ -1,0 +1,136 @@
+/*
+ * aliby_hip.h — C ABI of libaliby_hip.so (MI355X / gfx950).
+ *
+ * The reference (afermg/aliby) has no FFI: its seam is the Python step-callable
+ * protocol chosen by step-name prefix (src/aliby/pipe.py:47-72).
+ * This header is the boundary the Python step callables in `aliby_amd/` sit on;
+ * every entry point cites the reference interface whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every function returns an int status (ALIBY_OK == 0); on failure
+ *     aliby_last_error() returns a thread-local message.  The ctypes shim maps
+ *     codes to the Python exception types the reference raises
+ *     (ValueError / OverflowError / Exception, SURVEY.md §8b "Errors").
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - pointers marked [dev] are device pointers (hipMalloc / torch), [host] host.
+ *   - images are row-major; a "tile" is one [Y,X] label image plus C planes.
+ *   - pixel planes are ALIBY_U16 (uint16) or ALIBY_F32 (float).
+ *   - feature outputs are float64, written at out[row*ld + col].
+ *   - nothing here allocates inside a launch path: workspaces are explicit.
+ */
+#ifndef ALIBY_HIP_H
+#define ALIBY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALIBY_ABI_VERSION 1
+
+enum {
+  ALIBY_OK = 0,
+  ALIBY_ERR_INVALID = 1,      /* bad argument             -> ValueError    */
+  ALIBY_ERR_OVERFLOW = 2,     /* labels >= 65535          -> OverflowError */
+  ALIBY_ERR_HIP = 3,          /* HIP runtime failure      -> RuntimeError  */
+  ALIBY_ERR_TOO_LARGE = 4,    /* object exceeds workspace -> RuntimeError  */
+  ALIBY_ERR_UNSUPPORTED = 5   /* e.g. non-ufunc reducer   -> Exception     */
+};
+
+enum { ALIBY_U16 = 0, ALIBY_F32 = 1 };
+
+/* reduce_z operators — extraction/core/functions/loaders.py:110-127 ("max","add","div";
+ * "mean"/"median" are not ufuncs and raise in distributors.py:20-24). */
+enum { ALIBY_RED_MAX = 0, ALIBY_RED_ADD = 1, ALIBY_RED_DIV = 2 };
+
+typedef struct aliby_ctx aliby_ctx;
+
+/* One row per object, in (tile, label) order — the row order of
+ * process_tree_masks' ind_masks (extraction/extract.py:276-281). */
+typedef struct aliby_object {
+  int32_t tile;   /* index into the F tiles                               */
+  int32_t label;  /* 1..max(labels[tile])                                 */
+  int32_t y0, x0; /* bbox, inclusive; y0>y1 when the label is absent      */
+  int32_t y1, x1; /* bbox, exclusive                                      */
+  int32_t area;   /* pixel count (0 when absent)                          */
+  int32_t pad_;
+} aliby_object;
+
+/* ---- context / errors ------------------------------------------------- */
+int aliby_abi_version(void);
+const char* aliby_last_error(void);
+int aliby_ctx_create(int device, aliby_ctx** out);
+int aliby_ctx_destroy(aliby_ctx* ctx);
+int aliby_device_info(aliby_ctx* ctx, int* cu_count, int* lds_bytes, size_t* hbm_bytes,
+                      char* name, int name_len);
+
+/* plain memory helpers for callers without torch */
+int aliby_malloc(aliby_ctx* ctx, size_t bytes, void** dptr);
+int aliby_free(aliby_ctx* ctx, void* dptr);
+int aliby_memcpy_h2d(aliby_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int aliby_memcpy_d2h(aliby_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int aliby_memset(aliby_ctx* ctx, void* dst_dev, int value, size_t bytes, void* stream);
+int aliby_stream_sync(aliby_ctx* ctx, void* stream);
+
+/* ---- a4: tile stager --------------------------------------------------- */
+/* Tiler.get_fczyx / get_tp_channel / if_out_of_bounds_pad
+ * (src/aliby/tile/tiler.py:309-366,601-650; Tile.as_range tiles.py:151-166).
+ * stack [dev] is one time point [C,Z,Y,X]; rects [host] is F x (y0,x0,h,w) in
+ * image coordinates and may leave the image.  out [dev] is [F,C,Z,h,w].
+ * Partly outside -> np.pad(mode="median") semantics (per-line medians, rounded
+ * for integers); more than 25% outside along an axis -> the tile is NaN and
+ * flags[f] = 1 (out_f32 only).  All tiles share (h,w). */
+int aliby_crop_pad_u16(aliby_ctx* ctx, const uint16_t* stack, int C, int Z, int Y, int X,
+                       const int32_t* rects, int F, int h, int w, uint16_t* out,
+                       int32_t* nan_flags_host, void* stream);
+
+/* ---- a5: reduce_z ------------------------------------------------------- */
+/* reduce_z(pixels, ufunc, axis) (extraction/core/functions/distributors.py:6-24):
+ * in [dev] is [outer, Z, inner]; out [dev] is [outer, inner]; ufunc.reduce order
+ * (left fold over Z).  dtype preserved for max/add (u16 add wraps like numpy);
+ * div on u16 yields f32 per numpy true-divide semantics narrowed to f32. */
+int aliby_reduce_z(aliby_ctx* ctx, const void* in, int dtype, size_t outer, int Z, size_t inner,
+                   int op, void* out, int out_dtype, void* stream);
+
+/* ---- a7/a8: object table (replaces transform_2d_to_3d) ------------------ */
+/* process_tree_masks enumerates labels 1..mask.max() per tile
+ * (extract.py:276-281); transform_2d_to_3d (agora/utils/masks.py:35-37) explodes
+ * them to (N,Y,X) bool.  Here the label image stays as is and a compact table of
+ * per-object bboxes/areas is built instead.
+ * Step 1: per-tile maximum label -> max_host[F] (synchronises `stream`). */
+int aliby_label_max(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                    int32_t* max_host, void* stream);
+/* Step 2: fill table [dev] (n_obj rows = sum(max_host)), offsets_host[F+1] is the
+ * exclusive prefix sum of max_host.  Also copies the table to table_host if non-NULL
+ * (synchronises). */
+int aliby_object_table(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                       const int32_t* offsets_host, aliby_object* table_dev,
+                       aliby_object* table_host, void* stream);
+
+/* relabel_sequential (skimage, used at segment/dispatch.py:223 and extract.py:496):
+ * labels [dev, in place] renumbered 1..n in increasing original-label order,
+ * n_host[F] receives the per-tile count.  Raises ALIBY_ERR_OVERFLOW if n >= 65535
+ * (dispatch.py:230-233). */
+int aliby_relabel_sequential(aliby_ctx* ctx, uint16_t* labels, int F, int Y, int X,
+                             int32_t* n_host, void* stream);
+
+/* ---- a13: cp_measure single-image features ------------------------------ */
+/* Call site wrap_cp_measure_features (loaders.py:135-150): fun(mask.astype(uint16), pixels).
+ * planes [dev] is [F, C, Y, X] (already z-reduced); channel selects the plane.
+ * Rows of `out` follow the object table; columns start at col0 in the order
+ * returned by aliby_feature_names(). */
+int aliby_features_intensity(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
+                             int F, int C, int Y, int X, int channel,
+                             const aliby_object* table_dev, int n_obj, int max_area,
+                             int edge_measurements, double* out, int ld, int col0, void* stream);
+
+int aliby_features_sizeshape(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                             const aliby_object* table_dev, int n_obj, int max_h, int max_w,
+                             int max_area, double* out, int ld, int col0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIBY_HIP_H */
