@@ -65,6 +65,7 @@ _SIGNATURES = {
     "aliby_relabel_sequential": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "aliby_features_intensity": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_sizeshape": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "aliby_features_feret": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
 }
 
 _lib = None

@@ -355,6 +355,215 @@ __global__ __launch_bounds__(256) void k_shape_edt(EdtArgs a) {
   }
 }
 
+
+// -----------------------------------------------------------------------------------------------
+// Convex hulls.  Two hulls per object, both built from per-row extremes with Andrew's monotone
+// chain (exact integer cross products), four chains run concurrently on lane 0 of four waves:
+//   * "diamond" hull of the doubled coordinates (2r±1,2c),(2r,2c±1) of the object's pixels ->
+//     ConvexArea = number of bbox pixels whose centre is inside or on the hull
+//     (skimage.morphology.convex_hull_image, offset_coordinates=True, include_borders=True);
+//   * hull of the pixel centres -> Min/MaxFeretDiameter (centrosome.cpmorphology.feret_diameter:
+//     max = hull diameter, min = minimum width over hull edges) and, optionally, the hull itself
+//     for the minimum enclosing circle used by the Zernike family.
+// Workspace per workgroup (ints): rmin[2h+1] rmax[2h+1] cmin[h] cmax[h] | chains 4 x 2*(2h+2) points
+// -----------------------------------------------------------------------------------------------
+struct HullArgs {
+  const u16* labels;
+  int F, Y, X;
+  const aliby_object* tab;
+  int n_obj;
+  int max_h;
+  size_t cap_bytes;
+  unsigned char* gscratch;
+  double* out;      // sizeshape block (may be NULL)
+  int ld, col0;
+  double* feret_out;  // separate "feret" family block (may be NULL): [min, max]
+  int feret_ld, feret_col0;
+};
+
+struct P2 { int r, c; };
+
+__device__ __forceinline__ long long cross3(P2 o, P2 a, P2 b) {
+  return (long long)(a.r - o.r) * (b.c - o.c) - (long long)(a.c - o.c) * (b.r - o.r);
+}
+
+// monotone chain over rows [0,nrows): forward pass builds the "lower" chain, backward the "upper";
+// points of a row are (row, lo[row]) then (row, hi[row]); rows with lo>hi are empty.
+__device__ int chain_build(const int* lo, const int* hi, int nrows, bool forward, P2* st) {
+  int n = 0;
+  auto push = [&](P2 p) {
+    while (n >= 2 && cross3(st[n - 2], st[n - 1], p) <= 0) --n;
+    st[n++] = p;
+  };
+  if (forward) {
+    for (int r = 0; r < nrows; ++r) {
+      if (lo[r] > hi[r]) continue;
+      push(P2{r, lo[r]});
+      if (hi[r] != lo[r]) push(P2{r, hi[r]});
+    }
+  } else {
+    for (int r = nrows - 1; r >= 0; --r) {
+      if (lo[r] > hi[r]) continue;
+      push(P2{r, hi[r]});
+      if (hi[r] != lo[r]) push(P2{r, lo[r]});
+    }
+  }
+  return n;
+}
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void k_shape_hull(HullArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ int s_n[4];
+  __shared__ int red_i[8];
+  __shared__ double red_d[8];
+  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * a.cap_bytes) : lds_raw;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+  const int H = a.max_h;
+  int* rmin = reinterpret_cast<int*>(ws);           // doubled rows: 2H+1
+  int* rmax = rmin + (2 * H + 1);
+  int* cmin = rmax + (2 * H + 1);                   // pixel rows: H
+  int* cmax = cmin + H;
+  P2* chains = reinterpret_cast<P2*>(cmax + H);     // 4 chains
+  const int chain_cap = 2 * (2 * H + 1) + 2;
+
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    double* out = a.out ? a.out + (size_t)oi * a.ld + a.col0 : nullptr;
+    double* fout = a.feret_out ? a.feret_out + (size_t)oi * a.feret_ld + a.feret_col0 : nullptr;
+    if (o.area <= 0) {
+      if (tid == 0) {
+        if (out) { out[SS_ConvexArea] = NAN; out[SS_Solidity] = NAN; out[SS_MinFeretDiameter] = NAN; out[SS_MaxFeretDiameter] = NAN; }
+        if (fout) { fout[0] = NAN; fout[1] = NAN; }
+      }
+      continue;
+    }
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0;
+    const u16 L = (u16)o.label;
+    __syncthreads();
+    for (int r = tid; r < h; r += blockDim.x) { cmin[r] = INT_MAX; cmax[r] = -1; }
+    for (int r = tid; r < 2 * h + 1; r += blockDim.x) { rmin[r] = INT_MAX; rmax[r] = INT_MIN; }
+    __syncthreads();
+    for (int i = tid; i < h * w; i += blockDim.x) {
+      const int r = i / w, c = i % w;
+      if (lab[(size_t)(o.y0 + r) * a.X + o.x0 + c] == L) { atomicMin(&cmin[r], c); atomicMax(&cmax[r], c); }
+    }
+    __syncthreads();
+    // doubled rows R = 2r+1 +/- 1 shifted by +1 so that R in [0, 2h]: pixel row r -> R = 2r, 2r+1, 2r+2
+    for (int r = tid; r < h; r += blockDim.x) {
+      if (cmin[r] > cmax[r]) continue;
+      const int lo = 2 * cmin[r], hi = 2 * cmax[r];
+      atomicMin(&rmin[2 * r], lo);     atomicMax(&rmax[2 * r], hi);
+      atomicMin(&rmin[2 * r + 1], lo - 1); atomicMax(&rmax[2 * r + 1], hi + 1);
+      atomicMin(&rmin[2 * r + 2], lo); atomicMax(&rmax[2 * r + 2], hi);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      const int wv = tid >> 6;
+      int n;
+      if (wv == 0) n = chain_build(rmin, rmax, 2 * h + 1, true, chains + 0 * chain_cap);
+      else if (wv == 1) n = chain_build(rmin, rmax, 2 * h + 1, false, chains + 1 * chain_cap);
+      else if (wv == 2) n = chain_build(cmin, cmax, h, true, chains + 2 * chain_cap);
+      else n = chain_build(cmin, cmax, h, false, chains + 3 * chain_cap);
+      s_n[wv] = n;
+    }
+    __syncthreads();
+    // ---- convex area: bbox pixel centres (doubled: row 2r+1, col 2c) inside or on the diamond hull
+    const P2* lowD = chains;                 const int nl = s_n[0];
+    const P2* upD = chains + chain_cap;      const int nu = s_n[1];
+    int cnt = 0;
+    for (int i = tid; i < h * w; i += blockDim.x) {
+      const int r = i / w, c = i % w;
+      const P2 p{2 * r + 1, 2 * c};
+      bool in = true;
+      for (int k = 0; k + 1 < nl && in; ++k) in = cross3(lowD[k], lowD[k + 1], p) >= 0;
+      for (int k = 0; k + 1 < nu && in; ++k) in = cross3(upD[k], upD[k + 1], p) >= 0;
+      cnt += in ? 1 : 0;
+    }
+    const int CONVEX = block_sum_i32(cnt, red_i);
+
+    // ---- Feret diameters on the pixel-centre hull: vertices = low[0..nl2-2] ++ up[0..nu2-2]
+    const P2* lowC = chains + 2 * chain_cap; const int nl2 = s_n[2];
+    const P2* upC = chains + 3 * chain_cap;  const int nu2 = s_n[3];
+    const int K = (nl2 <= 1) ? 1 : (nl2 - 1) + (nu2 - 1);
+    auto vert = [&](int i) -> P2 { return (i < nl2 - 1 || nl2 <= 1) ? lowC[i] : upC[i - (nl2 - 1)]; };
+    double dmax = 0.0, wmin = INFINITY;
+    if (K >= 2) {
+      for (int i = tid; i < K; i += blockDim.x) {
+        const P2 pa = vert(i), pb = vert((i + 1) % K);
+        double far2 = 0.0;
+        long long wmax = 0;
+        for (int j = 0; j < K; ++j) {
+          const P2 q = vert(j);
+          const double dr = q.r - pa.r, dc = q.c - pa.c;
+          far2 = fmax(far2, dr * dr + dc * dc);
+          long long cr = cross3(pa, pb, q);
+          if (cr < 0) cr = -cr;
+          if (cr > wmax) wmax = cr;
+        }
+        dmax = fmax(dmax, sqrt(far2));
+        const double er = pb.r - pa.r, ec = pb.c - pa.c;
+        wmin = fmin(wmin, (double)wmax / sqrt(er * er + ec * ec));
+      }
+    }
+    const double DMAX = block_max_f64(dmax, red_d);
+    const double WMIN = -block_max_f64(-wmin, red_d);
+    if (tid == 0) {
+      const double fmin_ = (K <= 2) ? 0.0 : WMIN;
+      const double fmax_ = (K <= 1) ? 0.0 : DMAX;
+      if (out) {
+        out[SS_ConvexArea] = (double)CONVEX;
+        out[SS_Solidity] = (double)o.area / (double)CONVEX;
+        out[SS_MinFeretDiameter] = fmin_;
+        out[SS_MaxFeretDiameter] = fmax_;
+      }
+      if (fout) { fout[0] = fmin_; fout[1] = fmax_; }
+    }
+    __syncthreads();
+  }
+}
+
+static int launch_hull(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                       const aliby_object* table_dev, int n_obj, int max_h, double* out, int ld, int col0,
+                       double* fout, int fld, int fcol0, hipStream_t s) {
+  HullArgs a;
+  a.labels = labels; a.F = F; a.Y = Y; a.X = X; a.tab = table_dev; a.n_obj = n_obj; a.max_h = max_h;
+  a.out = out; a.ld = ld; a.col0 = col0; a.feret_out = fout; a.feret_ld = fld; a.feret_col0 = fcol0;
+  const size_t ints = (size_t)2 * (2 * max_h + 1) + 2 * (size_t)max_h;
+  const size_t chain_cap = 2 * (size_t)(2 * max_h + 1) + 2;
+  const size_t need = ints * sizeof(int) + 4 * chain_cap * sizeof(P2);
+  a.cap_bytes = (need + 15) & ~(size_t)15;
+  if (a.cap_bytes <= 96 * 1024) {
+    a.gscratch = nullptr;
+    if (a.cap_bytes > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)k_shape_hull<false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.cap_bytes));
+    hipLaunchKernelGGL((k_shape_hull<false>), dim3(n_obj), dim3(256), a.cap_bytes, s, a);
+  } else {
+    const int g = n_obj < 512 ? n_obj : 512;
+    int rc = aliby_ensure_scratch(ctx, (size_t)g * a.cap_bytes);
+    if (rc) return rc;
+    a.gscratch = (unsigned char*)ctx->scratch;
+    hipLaunchKernelGGL((k_shape_hull<true>), dim3(g), dim3(256), 0, s, a);
+  }
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+extern "C" int aliby_features_feret(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                                    const aliby_object* table_dev, int n_obj, int max_h, double* out,
+                                    int ld, int col0, void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (n_obj == 0) return ALIBY_OK;
+  ARG_CHECK(labels && table_dev && out, "NULL argument");
+  ARG_CHECK(F > 0 && Y > 0 && X > 0 && max_h >= 0, "bad shape");
+  ARG_CHECK(col0 >= 0 && col0 + 2 <= ld, "columns exceed row stride");
+  return launch_hull(ctx, labels, F, Y, X, table_dev, n_obj, max_h, nullptr, 0, 0, out, ld, col0,
+                     as_stream(stream));
+}
+
 static int pow2_at_least(int n, int lo) {
   int p = lo;
   while (p < n) p <<= 1;
@@ -416,6 +625,5 @@ extern "C" int aliby_features_sizeshape(aliby_ctx* ctx, const uint16_t* labels, 
     }
     KERNEL_CHECK();
   }
-  (void)max_area;
-  return ALIBY_OK;
+  return launch_hull(ctx, labels, F, Y, X, table_dev, n_obj, max_h, out, ld, col0, nullptr, 0, 0, s);
 }

@@ -139,3 +139,13 @@ class FeatureEngine:
             )
         )
         return 78
+
+    def feret(self, labels, table: ObjectTable, out, col0):
+        F, Y, X = labels.shape
+        _lib.check(
+            self.lib.aliby_features_feret(
+                self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj, table.max_h, _ptr(out),
+                out.stride(0), col0, _stream_ptr(),
+            )
+        )
+        return 2

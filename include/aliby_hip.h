@@ -130,6 +130,12 @@ int aliby_features_sizeshape(aliby_ctx* ctx, const uint16_t* labels, int F, int 
                              const aliby_object* table_dev, int n_obj, int max_h, int max_w,
                              int max_area, double* out, int ld, int col0, void* stream);
 
+/* cp_measure "feret" (get_core_measurements()["feret"], default feature list pipe_builder.py:49-56):
+ * out[:, col0] = MinFeretDiameter, out[:, col0+1] = MaxFeretDiameter. */
+int aliby_features_feret(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                         const aliby_object* table_dev, int n_obj, int max_h, double* out, int ld,
+                         int col0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,8 @@ def _compare(names, got, ref_dict, exact=(), skip=()):
         else:
             ok = np.allclose(g, r, rtol=RTOL, atol=1e-9, equal_nan=True)
         if not ok:
-            k = int(np.nanargmax(np.abs(g - r) / (np.abs(r) + 1e-12)))
+            err = np.nan_to_num(np.abs(g - r) / (np.abs(r) + 1e-12), nan=np.inf)
+            k = int(np.argmax(err))
             bad.append((name, k, g[k], r[k]))
     assert not bad, f"mismatch (name, object, hip, oracle): {bad[:8]} ... {len(bad)} columns"
 
