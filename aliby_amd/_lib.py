@@ -60,6 +60,8 @@ _SIGNATURES = {
     "aliby_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "aliby_memset": (_i, [_vp, _vp, _i, _sz, _vp]),
     "aliby_stream_sync": (_i, [_vp, _vp]),
+    "aliby_crop_pad_u16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "aliby_reduce_z": (_i, [_vp, _vp, _i, _sz, _i, _sz, _i, _vp, _i, _vp]),
     "aliby_label_max": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "aliby_object_table": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "aliby_relabel_sequential": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -84,22 +84,54 @@ class FeatureEngine:
         self.device = device
         self.ctx = _lib.default_context(device)
         self.lib = self.ctx.lib
+        self.profile = None  # set to {} to time kernel groups with HIP events on the launch stream
+
+    # ---------------------------------------------------------------- profiling
+    def timed(self, name: str):
+        """Context manager: brackets the enclosed launches with events on torch's current stream
+        (the stream every kernel is launched on) when profiling is enabled."""
+        eng = self
+
+        class _T:
+            def __enter__(self_):
+                if eng.profile is not None:
+                    self_.a = torch.cuda.Event(enable_timing=True)
+                    self_.b = torch.cuda.Event(enable_timing=True)
+                    self_.a.record()
+                return self_
+
+            def __exit__(self_, *exc):
+                if eng.profile is not None:
+                    self_.b.record()
+                    eng.profile.setdefault(name, []).append((self_.a, self_.b))
+                return False
+
+        return _T()
+
+    def collect_profile(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in (self.profile or {}).items():
+            out[name] = {"ms_total": float(sum(a.elapsed_time(b) for a, b in evs)), "launches": len(evs)}
+        return out
 
     # ------------------------------------------------------------------ objects
     def object_table(self, labels: torch.Tensor) -> ObjectTable:
         F, Y, X = labels.shape
         lib, h = self.lib, self.ctx.handle
         mx = np.zeros(F, np.int32)
-        _lib.check(lib.aliby_label_max(h, _ptr(labels), F, Y, X, _ptr(mx), _stream_ptr()))
+        with self.timed("object_table"):
+            _lib.check(lib.aliby_label_max(h, _ptr(labels), F, Y, X, _ptr(mx), _stream_ptr()))
         offsets = np.zeros(F + 1, np.int32)
         np.cumsum(mx, out=offsets[1:])
         n_obj = int(offsets[-1])
         host = np.zeros(n_obj, _lib.OBJECT_DTYPE)
         dev = torch.empty(max(n_obj, 1) * 32, dtype=torch.uint8, device=labels.device)
         if n_obj:
-            _lib.check(
-                lib.aliby_object_table(h, _ptr(labels), F, Y, X, _ptr(offsets), _ptr(dev), _ptr(host), _stream_ptr())
-            )
+            with self.timed("object_table"):
+                _lib.check(
+                    lib.aliby_object_table(h, _ptr(labels), F, Y, X, _ptr(offsets), _ptr(dev), _ptr(host), _stream_ptr())
+                )
         present = host["area"] > 0
         if present.any():
             hh = (host["y1"] - host["y0"])[present]
@@ -121,31 +153,34 @@ class FeatureEngine:
 
     def intensity(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, edge_measurements=True):
         F, Cn, Y, X = planes.shape
-        _lib.check(
+        with self.timed("intensity"):
+          _lib.check(
             self.lib.aliby_features_intensity(
                 self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel), _ptr(table.dev),
                 table.n_obj, table.max_area, 1 if edge_measurements else 0, _ptr(out), out.stride(0), col0,
                 _stream_ptr(),
             )
-        )
+          )
         return len(feat.intensity_names(edge_measurements))
 
     def sizeshape(self, labels, table: ObjectTable, out, col0):
         F, Y, X = labels.shape
-        _lib.check(
+        with self.timed("sizeshape"):
+          _lib.check(
             self.lib.aliby_features_sizeshape(
                 self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj, table.max_h, table.max_w,
                 table.max_area, _ptr(out), out.stride(0), col0, _stream_ptr(),
             )
-        )
+          )
         return 78
 
     def feret(self, labels, table: ObjectTable, out, col0):
         F, Y, X = labels.shape
-        _lib.check(
+        with self.timed("feret"):
+          _lib.check(
             self.lib.aliby_features_feret(
                 self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj, table.max_h, _ptr(out),
                 out.stride(0), col0, _stream_ptr(),
             )
-        )
+          )
         return 2

@@ -1,0 +1,120 @@
+"""
+Metric registry: instruction -> HIP kernel launch(es) writing a block of columns.
+
+Plays the role of the reference's CELL_FUNS / REDUCTION_FUNS registries
+(src/extraction/core/functions/loaders.py:28-79,110-127): names are the cp_measure feature names
+bound at loaders.py:71-77 plus the in-repo cell.py metrics (loaders.py:19-25).  A name that is not
+registered raises KeyError, as `CELL_FUNS[metric]` does (extract.py:147-153).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from aliby_amd import _lib
+from aliby_amd.extraction import features as feat
+from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+_RED = {"max": _lib.RED_MAX, "add": _lib.RED_ADD, "div": _lib.RED_DIV}
+
+
+class PlaneCache:
+    """z-reduced planes [F,C,Y,X], one reduction per distinct red_z instead of one per call
+    (the reference redoes it for every object x instruction, extract.py:105-107)."""
+
+    def __init__(self, eng, planes):
+        self.eng = eng
+        self.tensor, self.dtype = planes  # [F,C,Z,Y,X]
+        if self.tensor.ndim != 5:
+            raise Exception(f"pixels must be [F,C,Z,Y,X], got {tuple(self.tensor.shape)}")
+        self._cache = {}
+
+    def get(self, red_z):
+        if red_z in self._cache:
+            return self._cache[red_z]
+        if red_z not in _RED:
+            # np.mean / np.median / None are not ufuncs: distributors.py:20-24 raises
+            raise Exception(f"{red_z} is an invalid reducer.")
+        F, C, Z, Y, X = self.tensor.shape
+        op = _RED[red_z]
+        if Z == 1 and op == _lib.RED_MAX:
+            out, dt = self.tensor.reshape(F, C, Y, X), self.dtype
+        else:
+            dt = self.dtype if op == _lib.RED_MAX else _lib.F32
+            out = torch.empty((F, C, Y, X), dtype=torch.uint16 if dt == _lib.U16 else torch.float32,
+                              device=self.tensor.device)
+            _lib.check(
+                self.eng.lib.aliby_reduce_z(self.eng.ctx.handle, _ptr(self.tensor), self.dtype, F * C, Z, Y * X, op,
+                                            _ptr(out), dt, _stream_ptr())
+            )
+        self._cache[red_z] = (out, dt)
+        return out, dt
+
+
+def _mono_columns(metric, kw):
+    if metric in MONO:
+        return MONO[metric]["names"](kw)
+    raise KeyError(metric)
+
+
+def _launch_intensity(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.intensity(labels, plane, dt, ch, table, out, col0, edge_measurements=kw.get("edge_measurements", True))
+
+
+def _launch_sizeshape(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.sizeshape(labels, table, out, col0)
+
+
+def _launch_feret(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.feret(labels, table, out, col0)
+
+
+# name -> {names(kw) -> list[str] | None (scalar), launch, needs_pixels}
+MONO = {
+    "intensity": dict(names=lambda kw: feat.intensity_names(kw.get("edge_measurements", True)),
+                      launch=_launch_intensity, needs_pixels=True),
+    "sizeshape": dict(names=lambda kw: feat.sizeshape_names(), launch=_launch_sizeshape, needs_pixels=False),
+    "feret": dict(names=lambda kw: feat.feret_names(), launch=_launch_feret, needs_pixels=False),
+}
+MULTI = {}
+
+
+def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=False):
+    """Run every instruction over every object; returns (matrix [n_obj, n_cols] on device, blocks)."""
+    blocks, specs = [], []
+    col = 0
+    for inst in instructions:
+        metric = inst[-1]
+        kw = dict(cp_measure_kwargs.get(metric, {}))
+        reg = (MULTI if multi and inst[1] == "None" else MONO)
+        if metric not in reg:
+            raise KeyError(metric)
+        names = reg[metric]["names"](kw)
+        blocks.append((col, names))
+        specs.append((inst, reg[metric], kw, col))
+        col += 1 if names is None else len(names)
+    out = eng.new_output(table.n_obj, col)
+    cache = PlaneCache(eng, planes) if planes is not None else None
+    for inst, reg, kw, col0 in specs:
+        if multi:
+            (ch0, ch1), red_ch, red_z = inst[0], inst[1], inst[2]
+            if red_ch == "None":
+                plane, dt = cache.get(red_z)
+                reg["launch"](eng, labels, table, plane, dt, (ch0, ch1), out, col0, kw)
+            else:
+                raise NotImplementedError(
+                    "channel-combining multi instructions (extract.py:227-235) are not built; "
+                    "the builder only emits red_ch='None' (pipe_builder.py:33-43)"
+                )
+        else:
+            ch, red_z = inst[0], inst[1]
+            if ch == "None" or not reg["needs_pixels"]:
+                if ch != "None" and cache is not None:
+                    cache.get(red_z)  # the reference would still reduce (and raise on a bad reducer)
+                reg["launch"](eng, labels, table, None, 0, None, out, col0, kw)
+            else:
+                if cache is None:
+                    raise Exception("pixels are required for this instruction")
+                plane, dt = cache.get(red_z)
+                reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw)
+    return out, blocks

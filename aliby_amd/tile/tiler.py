@@ -1,0 +1,239 @@
+"""
+TCZYX -> FCZYX tile stager on the GPU, behind the reference Tiler's interface.
+
+Mirrors src/aliby/tile/tiler.py: `dispatch_tiler` (56-72), `Tiler.from_image` (251-271),
+`run_tp`/`_run_tp` (393-448), `get_fczyx` (309-333), `get_tp_channel` (335-366),
+`if_out_of_bounds_pad` (601-650), `get_center` (699-718).  The crop / median-pad arithmetic runs in
+aliby_amd/csrc/stager.hip through the C ABI (aliby_crop_pad_u16); the returned NumPy block is also
+registered in aliby_amd.devcache so that segment/extract steps reuse the device copy.
+
+Out of scope this round: trap detection (`segment_traps`) and drift estimation
+(`find_drift`, phase cross-correlation).  With `tile_size` set, tile centres must be given through
+`trap_locations=[(y,x), ...]`; otherwise the reference's own fallback (one centre tile) is used.
+"""
+
+from __future__ import annotations
+
+import logging
+import warnings
+from functools import partial
+from time import perf_counter
+
+import numpy as np
+
+from aliby_amd import devcache
+from aliby_amd.tile.tiles import TileLocations
+
+TILER_DEFAULTS = {"tile_size": 117, "ref_channel": 0, "ref_z": 0, "track_drift": True}
+
+
+class TilerParameters:
+    """Defaults of the reference's TilerParameters (tiler.py:45-53)."""
+
+    _defaults = dict(TILER_DEFAULTS)
+
+    def __init__(self, **kwargs):
+        params = dict(self._defaults)
+        params.update(kwargs)
+        for k, v in params.items():
+            setattr(self, k, v)
+        self._keys = list(params)
+
+    def to_dict(self):
+        return {k: getattr(self, k) for k in self._keys}
+
+    @classmethod
+    def default(cls, **kwargs):
+        return cls(**kwargs)
+
+
+class ImageArray:
+    """Minimal Image: `.data` is a 5-D TCZYX array-like, `.meta` a dict (io/image.py contract)."""
+
+    def __init__(self, source, **kwargs):
+        if isinstance(source, dict):
+            source = source.get("array", source.get("path"))
+        if isinstance(source, (str, bytes)) or hasattr(source, "__fspath__"):
+            path = str(source)
+            if path.endswith(".npy"):
+                source = np.load(path, mmap_mode="r")
+            else:
+                raise NotImplementedError(
+                    "image ingest from TIFF/zarr (src/aliby/io/image.py) is SURVEY §8f-2 and not built; "
+                    "pass a TCZYX array or a .npy path as image_kwargs['source']"
+                )
+        if source.ndim != 5:
+            raise ValueError(f"expected a 5-D TCZYX array, got shape {source.shape}")
+        self.data = source
+        self.meta = dict(kwargs.get("meta", {}))
+
+
+def dispatch_image(source):
+    return ImageArray
+
+
+def dispatch_tiler(kind, kwargs: dict):
+    """Returns a constructor that needs an Image (tiler.py:56-72).  kind="crop" is not built."""
+    keys = set(TILER_DEFAULTS)
+    tiler_kwargs = {k: v for k, v in kwargs.items() if k in keys}
+    extra = {k: v for k, v in kwargs.items() if k not in keys}
+    if kind == "crop":
+        raise NotImplementedError("CropTiler (tiler.py:138-189) is outside the hot path (SURVEY §2 row 4)")
+    return partial(Tiler.from_image, parameters=TilerParameters(**tiler_kwargs), **extra)
+
+
+def get_center(pixels_shape):
+    yx = tuple(pixels_shape[-2:])
+    return TileLocations.from_tiler_init((tuple(s // 2 for s in yx),), max_size=yx)
+
+
+class Tiler:
+    def __init__(self, pixels, meta, parameters, tile_locs=None, trap_locations=None, **kwargs):
+        self._parameters = parameters
+        for k, v in parameters.to_dict().items():
+            setattr(self, k, v)
+        self.pixels = pixels
+        self.meta = meta
+        self.channels = list(range(pixels.shape[-4]))
+        if self.tile_size is not None:
+            idx = parameters.ref_channel
+            if isinstance(idx, str):
+                idx = self.channels.index(idx)
+            self.ref_channel_index = idx
+        self.tile_locs = tile_locs
+        self._trap_locations = trap_locations
+        self.tile_size = self.tile_size or tuple(self.pixels.shape[-2:])
+        if isinstance(self.tile_size, int):
+            self.tile_size = (self.tile_size, self.tile_size)
+        self.no_processed = 0
+        self._dev_stack = {}  # tp -> device [C,Z,Y,X] (keeps the last two, like load_image's lru_cache(2))
+        self._engine = None
+
+    @classmethod
+    def from_image(cls, image, parameters, **kwargs):
+        return cls(image.data, image.meta, parameters, **kwargs)
+
+    @property
+    def parameters(self):
+        return self._parameters
+
+    @property
+    def shape(self):
+        return self.pixels.shape
+
+    # ------------------------------------------------------------------ protocol
+    def run_tp(self, tp: int, **kwargs):
+        t1 = perf_counter()
+        out = self._run_tp(tp, **kwargs)
+        logging.getLogger("aliby").debug(f"Tiler.run_tp took {(perf_counter() - t1):.4f}s")
+        return out
+
+    def _run_tp(self, tp: int):
+        if self.no_processed == 0:
+            if hasattr(self, "ref_channel_index"):
+                self.tile_locs = self._areas_of_interest()
+            else:
+                self.tile_locs = get_center(self.pixels.shape)
+        n_drifts = len(self.tile_locs.drifts)
+        if self.no_processed != n_drifts:
+            warnings.warn("Tiler: the number of processed tiles and the number of drifts calculated do not match.")
+            self.no_processed = n_drifts
+        if not hasattr(self, "calculate_drift"):
+            self.calculate_drift = False
+        if self.calculate_drift:
+            raise NotImplementedError("drift estimation (tiler.py:284-307) is SURVEY §8f-3 and not built")
+        drift = [0.0, 0.0]
+        if 0 < tp < len(self.tile_locs.drifts):
+            self.tile_locs.drifts[tp] = drift
+        else:
+            self.tile_locs.drifts.append(drift)
+        self.no_processed = tp + 1
+        return {"drift": self.tile_locs.to_dict(tp), "pixels": self.get_fczyx(tp)}
+
+    def _areas_of_interest(self):
+        """set_areas_of_interest (tiler.py:653-696) with explicit centres instead of trap detection."""
+        shape = self.pixels.shape[-2:]
+        tmin = min(self.tile_size)
+        if self._trap_locations is not None and min(shape) // 2 > tmin // 2:
+            half, max_size = tmin // 2, min(shape)
+            locs = [
+                [a, b]
+                for a, b in self._trap_locations
+                if half < a < max_size - half and half < b < max_size - half
+            ]
+            return TileLocations.from_tiler_init(locs, self.tile_size, max_size)
+        if min(shape) // 2 > tmin // 2:
+            warnings.warn("Trap detection is not built (SURVEY §8f-3), falling back to center tile.")
+        return get_center(self.pixels.shape)
+
+    # --------------------------------------------------------------------- pixels
+    def _device_stack(self, tp: int):
+        import torch
+
+        if tp in self._dev_stack:
+            return self._dev_stack[tp]
+        block = self.pixels[tp]
+        if hasattr(block, "compute"):
+            block = block.compute(scheduler="synchronous")
+        if isinstance(block, torch.Tensor):
+            dev = block.cuda()
+        else:
+            block = np.ascontiguousarray(block)
+            if block.dtype != np.uint16:
+                raise NotImplementedError(
+                    f"stager handles uint16 stacks (the reference's fixtures, SURVEY §3.3); got {block.dtype}"
+                )
+            dev = torch.from_numpy(block).cuda()
+        if len(self._dev_stack) >= 2:
+            self._dev_stack.pop(next(iter(self._dev_stack)))
+        self._dev_stack[tp] = dev
+        return dev
+
+    def rects(self, tp: int) -> np.ndarray:
+        """[F,4] (y0, x0, h, w) from Tile.as_range (first axis = rows, tiles.py:151-166)."""
+        rows = []
+        for tile in self.tile_locs:
+            ys, xs = tile.as_range(tp)
+            rows.append((ys.start, xs.start, ys.stop - ys.start, xs.stop - xs.start))
+        return np.asarray(rows, dtype=np.int32).reshape(-1, 4)
+
+    def get_fczyx_device(self, tp: int):
+        """(device uint16 [F,C,Z,h,w], nan_flags[F]) — crop + median pad on the GPU."""
+        import torch
+
+        from aliby_amd import _lib
+        from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr
+
+        if self._engine is None:
+            self._engine = FeatureEngine()
+        stack = self._device_stack(tp)
+        C, Z, Y, X = stack.shape
+        rects = self.rects(tp)
+        F = len(rects)
+        h, w = (int(rects[0, 2]), int(rects[0, 3])) if F else (0, 0)
+        out = torch.empty((F, C, Z, h, w), dtype=torch.uint16, device=stack.device)
+        flags = np.zeros(max(F, 1), np.int32)
+        if F:
+            _lib.check(
+                self._engine.lib.aliby_crop_pad_u16(
+                    self._engine.ctx.handle, _ptr(stack), C, Z, Y, X, _ptr(rects), F, h, w, _ptr(out), _ptr(flags),
+                    _stream_ptr(),
+                )
+            )
+        return out, flags[:F]
+
+    def get_fczyx(self, tp: int, drift: bool = True) -> np.ndarray:
+        dev, flags = self.get_fczyx_device(tp)
+        host = dev.cpu().numpy()
+        if flags.any():
+            # if_out_of_bounds_pad returns float NaN tiles; np.stack then upcasts the block (tiler.py:642-650)
+            host = host.astype(np.float64)
+            host[flags.astype(bool)] = np.nan
+            return host
+        return devcache.attach(host, dev, kind="pixels")
+
+    def get_tp_channel(self, tp: int, c: int, drift: bool = True) -> np.ndarray:
+        return self.get_fczyx(tp)[:, c]
+
+    def get_tile_data(self, tile_id: int, tp: int, c: int) -> np.ndarray:
+        return self.get_fczyx(tp)[tile_id, c]

@@ -1,0 +1,234 @@
+"""
+bench.py — whole-job throughput of the segmentation + cp_measure hot path on synthetic TCZYX stacks.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of B synthetic FOVs per GPU (config 2 of
+BASELINE.json: 1024x1024, 5 channels, ~250 nuclei per FOV), inputs already resident in HBM:
+    stage (crop/pad) -> [segment] -> object table -> every feature family of the pipeline tree -> D2H.
+FOVs are independent, so ranks shard them with no data-path collective ("scaling": "weak").
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def build_tree(channels, supported):
+    """The builder's trees (pipe_builder.py:108-129), restricted to the families already built."""
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    pipe = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=list(channels))
+    mono = pipe["steps"]["extract_nuclei"]["tree"]
+    multi = pipe["steps"]["extractmulti_nuclei"]["tree"]
+    missing = set()
+
+    def keep(tree, reg):
+        out = {}
+        for k, v in tree.items():
+            if isinstance(v, dict):
+                sub = keep(v, reg)
+                if sub:
+                    out[k] = sub
+            else:
+                kept = [m for m in v if m in reg]
+                missing.update(m for m in v if m not in reg)
+                if kept:
+                    out[k] = kept
+        return out
+
+    from aliby_amd.extraction import families
+
+    return keep(mono, families.MONO), keep(multi, families.MULTI), sorted(missing)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--fovs", type=int, default=32, help="FOVs per step per GPU")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic FOVs generated (replicated to --fovs)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from aliby_amd import _lib, synth
+    from aliby_amd.extraction.batch import extract_batch
+    from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr
+
+    eng = FeatureEngine(local_rank)
+    C, Z, Y, X = 5, 1, args.size, args.size
+    B = args.fovs
+    mono_tree, multi_tree, missing = build_tree(range(C), None)
+
+    # ---- synthetic inputs, resident in HBM -------------------------------------------------
+    base = [synth.make_fov(2, rank * args.distinct + i, shape=(Y, X)) for i in range(args.distinct)]
+    stacks = torch.empty((B, C, Z, Y, X), dtype=torch.uint16, device="cuda")
+    truth = torch.empty((B, Y, X), dtype=torch.uint16, device="cuda")
+    for b in range(B):
+        src = base[b % args.distinct]
+        stacks[b] = torch.from_numpy(src["pixels"]).cuda()
+        truth[b] = torch.from_numpy(src["nuclei"]).cuda()
+    n_obj_per_fov = float(np.mean([int(s["nuclei"].max()) for s in base]))
+    tiles = torch.empty_like(stacks)
+    labels = torch.empty_like(truth)
+    rect = np.array([[0, 0, Y, X]], np.int32)
+    flags = np.zeros(1, np.int32)
+    torch.cuda.synchronize()
+
+    eng.profile = {}
+
+    def step():
+        # (a4) stage: monotile crop of every FOV (B*C planes as channels of one stack)
+        with eng.timed("stage_crop_pad"):
+            _lib.check(eng.lib.aliby_crop_pad_u16(eng.ctx.handle, _ptr(stacks), B * C, Z, Y, X, _ptr(rect), 1, Y, X,
+                                                  _ptr(tiles), _ptr(flags), _stream_ptr()))
+        # (a6) segmentation: NOT YET IN THE TIMED PATH — labels are copied from the synthetic ground truth
+        labels.copy_(truth)
+        planes = (tiles.view(B, C, Z, Y, X), _lib.U16)
+        m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
+        out = [m1.cpu()]
+        if multi_tree:
+            m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+            out.append(m2.cpu())
+        return out, table
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, table = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tiles_per_s = world * B * args.steps / dt
+    n_cols = sum(o.shape[1] for o in out)
+
+    # ---- per-kernel-group device time (HIP events on the launch stream) -----------------------
+    prof = eng.collect_profile()
+    dominant = max(prof, key=lambda k: prof[k]["ms_total"]) if prof else None
+    roof = None
+    if dominant:
+        launches = prof[dominant]["launches"]
+        avg_ms = prof[dominant]["ms_total"] / launches
+        P = Y * X
+        n_obj = table.n_obj
+        alg = {
+            "stage_crop_pad": 2.0 * B * C * Z * P * 2,
+            "intensity": B * P * 2 * 2 + n_obj * 21 * 8,
+            "sizeshape": B * P * 2 + n_obj * 78 * 8,
+            "feret": B * P * 2 + n_obj * 2 * 8,
+        }.get(dominant, B * P * 2 * 2)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "alg_bytes_per_launch": alg, "avg_launch_ms": round(avg_ms, 4), "launches": launches}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(base[0], mono_tree, multi_tree, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "FOV tiles/sec (whole node)",
+            "value": round(tiles_per_s, 3),
+            "unit": "tiles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u16 pixels / f64 accumulators",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {B} FOV/step/GPU, {Y}x{X}, {C} channels, Z={Z}, ~{n_obj_per_fov:.0f} nuclei/FOV "
+                            f"({args.distinct} distinct FOVs replicated)",
+                "features": sorted({m for v in mono_tree.values() for vv in v.values() for m in vv}
+                                   | {m for v in multi_tree.values() for vv in v.values() for vvv in vv.values() for m in vvv}),
+                "features_missing": missing,
+                "segmentation": "excluded (labels = synthetic ground truth); to be added",
+                "feature_vectors_per_s": round(tiles_per_s * n_obj_per_fov, 1),
+                "columns": n_cols,
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: round(v["ms_total"] / args.steps, 3) for k, v in prof.items()},
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(fov, mono_tree, multi_tree, seconds):
+    """Oracle in the reference's structure (per-object full-frame masks, one call per
+    object x instruction), on a bounded sample of objects of FOV 0; 1 core."""
+    from oracle import aliby_extract as ox
+
+    masks = [fov["nuclei"]]
+    pixels = fov["pixels"][None]
+    n_total = int(fov["nuclei"].max())
+    t0 = time.perf_counter()
+    ox.process_tree_masks(mono_tree, masks, pixels, ox.extract_tree, max_objects=1)
+    if multi_tree:
+        ox.process_tree_masks(multi_tree, masks, pixels, ox.extract_tree_multi, max_objects=1)
+    per_obj = time.perf_counter() - t0
+    k = int(max(1, min(n_total, seconds / max(per_obj, 1e-3))))
+    t0 = time.perf_counter()
+    ox.process_tree_masks(mono_tree, masks, pixels, ox.extract_tree, max_objects=k)
+    if multi_tree:
+        ox.process_tree_masks(multi_tree, masks, pixels, ox.extract_tree_multi, max_objects=k)
+    t = time.perf_counter() - t0
+    # the (N,Y,X) bool explosion is paid once per step regardless of k; scale only the per-object part
+    t0 = time.perf_counter()
+    ox.transform_2d_to_3d(fov["nuclei"])
+    t_explode = time.perf_counter() - t0
+    n_steps = 1 + (1 if multi_tree else 0)
+    per_tile = (t - n_steps * t_explode) * n_total / k + n_steps * t_explode
+    return {"value": round(1.0 / per_tile, 5), "unit": "tiles/s", "cores": 1, "kind": "port",
+            "sample": f"oracle in reference structure on the first {k} of {n_total} objects of FOV 0 "
+                      f"({t:.1f} s measured, extrapolated to the full tile; segmentation excluded)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -134,7 +134,7 @@ def extract_tree_multi(tileid_instructions, masks, pixels, cp_measure_kwargs=Non
     return result
 
 
-def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, limit=None):
+def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, limit=None, max_objects=None):
     if not isinstance(masks, list):
         masks = [masks]
     instructions = kv(flatten(tree))
@@ -143,6 +143,8 @@ def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, 
         if len(m):
             for mask_i in range(1, int(m.max()) + 1):
                 ind_masks.append((tile_i, mask_i))
+    if max_objects is not None:  # bounded sample for the cpu_baseline leg of bench.py
+        ind_masks = ind_masks[:max_objects]
     tileid_instructions = tuple(product(ind_masks, instructions))
     result = measure_fn(tileid_instructions, masks, pixels, cp_measure_kwargs=cp_measure_kwargs, limit=limit)
     return tileid_instructions, result
