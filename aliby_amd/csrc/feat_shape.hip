@@ -193,8 +193,16 @@ __global__ __launch_bounds__(256) void k_shape_core(ShapeArgs a) {
       out[SS_FormFactor] = fpa / (perim * perim);
       out[SS_Perimeter] = perim;
       // inertia tensor (skimage.measure.inertia_tensor): rows/cols = (r, c) axes
-      const double mu00 = MU[0], mu02 = MU[2], mu20 = MU[8], mu11 = MU[5];
-      const double Ta = mu02 / mu00, Tb = -mu11 / mu00, Tc = mu20 / mu00;
+      // second-order central moments from exact integer sums (n*S2 - S1*S1): the isotropic case
+      // (Ta == Tc, Tb == 0) that skimage's orientation branches on is then decided exactly
+      const double mu00 = MU[0];
+      const __int128 n_ = (__int128)llrint(M[0]);
+      const __int128 Sr = (__int128)llrint(M[4]), Sc = (__int128)llrint(M[1]);
+      const __int128 Srr = (__int128)llrint(M[8]), Scc = (__int128)llrint(M[2]), Src = (__int128)llrint(M[5]);
+      const __int128 I20 = n_ * Srr - Sr * Sr, I02 = n_ * Scc - Sc * Sc, I11 = n_ * Src - Sr * Sc;
+      const double nn = (double)n_ * (double)n_;
+      const double Ta = (double)I02 / nn, Tb = -(double)I11 / nn, Tc = (double)I20 / nn;
+      const bool iso = (I02 == I20);
       out[SS_Inertia + 0] = Ta;
       out[SS_Inertia + 1] = Tb;
       out[SS_Inertia + 2] = Tb;
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(256) void k_shape_core(ShapeArgs a) {
       out[SS_MinorAxisLength] = 4.0 * sqrt(l2);
       out[SS_Eccentricity] = (l1 == 0.0) ? 0.0 : sqrt(1.0 - l2 / l1);
       double orient;
-      if (Ta - Tc == 0.0) orient = (Tb < 0.0) ? -M_PI / 4.0 : M_PI / 4.0;
+      if (iso) orient = (I11 > 0) ? -M_PI / 4.0 : M_PI / 4.0;  // Tb < 0  <=>  I11 > 0
       else orient = 0.5 * atan2(-2.0 * Tb, Tc - Ta);
       out[SS_Orientation] = orient * (180.0 / M_PI);
       for (int p = 0; p < 3; ++p)
