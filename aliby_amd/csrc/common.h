@@ -150,6 +150,59 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n2) {
   __syncthreads();
 }
 
+// sum a K-vector of doubles over the block (blockDim.x <= 256); every thread gets the K sums in v[].
+// `lds` needs >= 4*K doubles.  Deterministic (fixed tree, waves folded in order).
+template <int K>
+__device__ __forceinline__ void block_sum_vec_all(double (&v)[K], double* lds) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = wave_sum(v[k]);
+    if (lane == 0) lds[wid * K + k] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double r = 0;
+    for (int i = 0; i < nw; ++i) r += lds[i * K + k];
+    v[k] = r;
+  }
+}
+
+// Order-preserving compaction slot for one "chunk" (one element per thread, in thread order):
+// returns base + number of set flags among lower-numbered threads; `base` is advanced by the chunk
+// total for every thread.  `wsum` is an LDS int[4].
+__device__ __forceinline__ int block_compact_slot(bool flag, int& base, int* wsum) {
+  const unsigned long long bal = __ballot(flag);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  __syncthreads();
+  if (lane == 0) wsum[wid] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < nw; ++i) { const int c = wsum[i]; if (i < wid) off += c; tot += c; }
+  const int pos = base + off + before;
+  base += tot;
+  return pos;
+}
+
+// In-place inclusive scan of n ints (LDS or global); all threads call.  `part` is an LDS int[256].
+__device__ __forceinline__ void block_inclusive_scan(int* a, int n, int* part) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int per = (n + nt - 1) / nt;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) { s += a[i]; a[i] = s; }
+  __syncthreads();
+  part[t] = s;
+  __syncthreads();
+  int off = 0;
+  for (int i = 0; i < t; ++i) off += part[i];
+  if (off) for (int i = lo; i < hi; ++i) a[i] += off;
+  __syncthreads();
+}
+
 __device__ __forceinline__ int next_pow2(int n) {
   int p = 1;
   while (p < n) p <<= 1;

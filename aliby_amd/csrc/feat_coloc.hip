@@ -1,0 +1,311 @@
+// feat_coloc.hip — cp_measure colocalisation metrics for one channel pair, one workgroup per object.
+//
+// Reference call site: wrap_cp_corr_features (extraction/core/functions/loaders.py:153-167),
+// `fun(pixels1, pixels2, mask)`, with the metric list of the builder's multi tree
+// (pipe_builder.py:33-43: pearson, costes, manders_fold, rwc) reached through measure_multi
+// (extraction/extract.py:222-226).  cp_measure 0.1.17 is not vendored; restated from CellProfiler's
+// MeasureColocalization (per-object branch):
+//   pearson      : r = Sxy / (sqrt(Sxx) sqrt(Syy)) about the object means; slope = Sxy / Sxx
+//   manders_fold : thresholds at thr% (15) of the object's maximum in each channel;
+//                  M1 = sum(f | f>=t1 & s>=t2) / sum(f | f>=t1)
+//   rwc          : dense ranks (ties share a rank) of both channels inside the object,
+//                  weight = (R - |r1-r2|)/R with R = max rank + 1, applied to the Manders sums
+//   costes       : orthogonal regression line + bisection on the candidate threshold ("Faster"
+//                  mode) until Pearson r of the below-threshold pixels changes sign, then Manders-style
+//                  fractions strictly above the thresholds.
+//
+// Data movement: the object's pixels of both planes are gathered once (order-preserving compaction)
+// into LDS (global scratch for objects larger than the LDS budget); every statistic is an fp64 block
+// reduction over that list; ranks come from one LDS bitonic sort per channel + binary searches.
+#include "common.h"
+
+typedef unsigned short u16;
+
+struct ColocArgs {
+  const u16* labels;
+  const void* planes;  // [F,C,Y,X]
+  int F, C, Y, X, ch0, ch1;
+  const aliby_object* tab;
+  int n_obj;
+  int cap;  // power of two >= max area
+  unsigned char* gscratch;
+  double* out;
+  int ld;
+  int col_pearson, col_manders, col_rwc, col_costes;  // -1 = not requested
+  double thr;        // percent of the maximum (15)
+  double scale_max;  // costes candidate scale (255)
+};
+
+template <typename T, bool GLOBAL>
+__global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ double vec[4 * 8];
+  __shared__ double red_d[8];
+  __shared__ float red_f[8];
+  __shared__ int red_i[8];
+  __shared__ int wsum[4];
+  __shared__ int part[256];
+
+  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * (size_t)a.cap * 20) : lds_raw;
+  float* fv = reinterpret_cast<float*>(ws);
+  float* sv = fv + a.cap;
+  float* S = sv + a.cap;
+  int* P = reinterpret_cast<int*>(S + a.cap);
+  int* r1 = P + a.cap;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    double* out = a.out + (size_t)oi * a.ld;
+    if (o.area <= 0) {
+      if (tid == 0) {
+        if (a.col_pearson >= 0) { out[a.col_pearson] = NAN; out[a.col_pearson + 1] = NAN; }
+        if (a.col_manders >= 0) { out[a.col_manders] = NAN; out[a.col_manders + 1] = NAN; }
+        if (a.col_rwc >= 0) { out[a.col_rwc] = NAN; out[a.col_rwc + 1] = NAN; }
+        if (a.col_costes >= 0) { out[a.col_costes] = NAN; out[a.col_costes + 1] = NAN; }
+      }
+      continue;
+    }
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const T* p0 = reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.ch0) * plane;
+    const T* p1 = reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.ch1) * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, npix = h * w;
+    const u16 L = (u16)o.label;
+
+    // ---- gather (raster order) ------------------------------------------------------------
+    __syncthreads();
+    int base = 0;
+    for (int i0 = 0; i0 < npix; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      bool in = false;
+      size_t idx = 0;
+      if (i < npix) {
+        idx = (size_t)(o.y0 + i / w) * a.X + (o.x0 + i % w);
+        in = lab[idx] == L;
+      }
+      const int pos = block_compact_slot(in, base, wsum);
+      if (in) { fv[pos] = px_load<T>(p0, idx); sv[pos] = px_load<T>(p1, idx); }
+    }
+    __syncthreads();
+    const int N = base;
+    const double dN = (double)N;
+
+    // ---- sums, maxima -------------------------------------------------------------------------
+    double acc[8];
+    float m1 = -INFINITY, m2 = -INFINITY;
+    acc[0] = acc[1] = 0;
+    for (int j = tid; j < N; j += blockDim.x) {
+      acc[0] += (double)fv[j]; acc[1] += (double)sv[j];
+      m1 = fmaxf(m1, fv[j]); m2 = fmaxf(m2, sv[j]);
+    }
+    double s2[2] = {acc[0], acc[1]};
+    block_sum_vec_all<2>(s2, vec);
+    const double mean1 = s2[0] / dN, mean2 = s2[1] / dN;
+    const float MAX1 = block_max_f32(m1, red_f), MAX2 = block_max_f32(m2, red_f);
+
+    if (a.col_pearson >= 0) {
+      double q[3] = {0, 0, 0};
+      for (int j = tid; j < N; j += blockDim.x) {
+        const double x = (double)fv[j] - mean1, y = (double)sv[j] - mean2;
+        q[0] += x * x; q[1] += y * y; q[2] += x * y;
+      }
+      block_sum_vec_all<3>(q, vec);
+      if (tid == 0) {
+        out[a.col_pearson] = q[2] / (sqrt(q[0]) * sqrt(q[1]));
+        out[a.col_pearson + 1] = q[2] / q[0];
+      }
+    }
+
+    // ---- Manders / RWC share thresholds and denominators ---------------------------------------
+    const double tff = (a.thr / 100.0) * (double)MAX1, tss = (a.thr / 100.0) * (double)MAX2;
+    double tot1 = 0, tot2 = 0;
+    int any_comb = 0;
+    if (a.col_manders >= 0 || a.col_rwc >= 0) {
+      double q[4] = {0, 0, 0, 0};
+      int anyc = 0;
+      for (int j = tid; j < N; j += blockDim.x) {
+        const double f = fv[j], s = sv[j];
+        const bool a1 = f >= tff, a2 = s >= tss;
+        if (a1) q[0] += f;
+        if (a2) q[1] += s;
+        if (a1 && a2) { q[2] += f; q[3] += s; anyc = 1; }
+      }
+      block_sum_vec_all<4>(q, vec);
+      any_comb = block_max_i32(anyc, red_i);
+      tot1 = q[0]; tot2 = q[1];
+      if (a.col_manders >= 0 && tid == 0) {
+        out[a.col_manders] = any_comb ? q[2] / tot1 : 0.0;
+        out[a.col_manders + 1] = any_comb ? q[3] / tot2 : 0.0;
+      }
+    }
+
+    if (a.col_rwc >= 0) {
+      const int n2 = next_pow2(N);
+      // channel 1: sort, distinct-prefix, dense rank per pixel
+      for (int i = tid; i < n2; i += blockDim.x) S[i] = (i < N) ? fv[i] : INFINITY;
+      block_bitonic_sort(S, n2);
+      for (int i = tid; i < N; i += blockDim.x) P[i] = (i > 0 && S[i] != S[i - 1]) ? 1 : 0;
+      __syncthreads();
+      block_inclusive_scan(P, N, part);
+      const int R1MAX = P[N - 1];
+      for (int j = tid; j < N; j += blockDim.x) {
+        const float v = fv[j];
+        int lo = 0, hi = N;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] < v) lo = mid + 1; else hi = mid; }
+        r1[j] = P[lo];
+      }
+      __syncthreads();
+      // channel 2
+      for (int i = tid; i < n2; i += blockDim.x) S[i] = (i < N) ? sv[i] : INFINITY;
+      block_bitonic_sort(S, n2);
+      for (int i = tid; i < N; i += blockDim.x) P[i] = (i > 0 && S[i] != S[i - 1]) ? 1 : 0;
+      __syncthreads();
+      block_inclusive_scan(P, N, part);
+      const int R2MAX = P[N - 1];
+      const double R = (double)(max(R1MAX, R2MAX) + 1);
+      double q[2] = {0, 0};
+      for (int j = tid; j < N; j += blockDim.x) {
+        const double f = fv[j], s = sv[j];
+        if (f >= tff && s >= tss) {
+          const float v = sv[j];
+          int lo = 0, hi = N;
+          while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] < v) lo = mid + 1; else hi = mid; }
+          const int di = abs(r1[j] - P[lo]);
+          const double wgt = (R - (double)di) * 1.0 / R;
+          q[0] += f * wgt; q[1] += s * wgt;
+        }
+      }
+      block_sum_vec_all<2>(q, vec);
+      if (tid == 0) {
+        out[a.col_rwc] = any_comb ? q[0] / tot1 : 0.0;
+        out[a.col_rwc + 1] = any_comb ? q[1] / tot2 : 0.0;
+      }
+    }
+
+    if (a.col_costes >= 0) {
+      // regression line through the non-zero pixels
+      double q[3] = {0, 0, 0};
+      for (int j = tid; j < N; j += blockDim.x) {
+        const double f = fv[j], s = sv[j];
+        if (f > 0 || s > 0) { q[0] += 1; q[1] += f; q[2] += s; }
+      }
+      block_sum_vec_all<3>(q, vec);
+      const double nnz = q[0], xmean = q[1] / nnz, ymean = q[2] / nnz, zmean = (q[1] + q[2]) / nnz;
+      double v3[3] = {0, 0, 0};
+      for (int j = tid; j < N; j += blockDim.x) {
+        const double f = fv[j], s = sv[j];
+        if (f > 0 || s > 0) {
+          const double dx = f - xmean, dy = s - ymean, dz = (f + s) - zmean;
+          v3[0] += dx * dx; v3[1] += dy * dy; v3[2] += dz * dz;
+        }
+      }
+      block_sum_vec_all<3>(v3, vec);
+      const double xvar = v3[0] / (nnz - 1), yvar = v3[1] / (nnz - 1), zvar = v3[2] / (nnz - 1);
+      const double covar = 0.5 * (zvar - (xvar + yvar));
+      const double denom = 2 * covar;
+      const double num = (yvar - xvar) + sqrt((yvar - xvar) * (yvar - xvar) + 4 * (covar * covar));
+      const double ca = num / denom, cb = ymean - ca * xmean;
+      double left = 1, right = a.scale_max;
+      double mid = floor((right - left) / (6.0 / 5.0)) + left;
+      double lastmid = 0, valid = 1;
+      for (int it = 0; it < 200 && lastmid != mid; ++it) {
+        const double t1 = mid / a.scale_max, t2 = ca * t1 + cb;
+        double c3[3] = {0, 0, 0};
+        for (int j = tid; j < N; j += blockDim.x) {
+          const double f = fv[j], s = sv[j];
+          if (f < t1 || s < t2) { c3[0] += 1; c3[1] += f; c3[2] += s; }
+        }
+        block_sum_vec_all<3>(c3, vec);
+        if (c3[0] <= 2) {
+          left = mid - 1;
+        } else {
+          const double mx = c3[1] / c3[0], my = c3[2] / c3[0];
+          double p3[3] = {0, 0, 0};
+          for (int j = tid; j < N; j += blockDim.x) {
+            const double f = fv[j], s = sv[j];
+            if (f < t1 || s < t2) { const double dx = f - mx, dy = s - my; p3[0] += dx * dx; p3[1] += dy * dy; p3[2] += dx * dy; }
+          }
+          block_sum_vec_all<3>(p3, vec);
+          const double nx = sqrt(p3[0]), ny = sqrt(p3[1]);
+          double r = NAN;
+          if (nx != 0 && ny != 0) r = fmax(fmin(p3[2] / (nx * ny), 1.0), -1.0);
+          if (r < 0) left = mid - 1;
+          else if (r >= 0) { right = mid + 1; valid = mid; }
+        }
+        lastmid = mid;
+        if (right - left > 6) mid = floor((right - left) / (6.0 / 5.0)) + left;
+        else mid = floor((right - left) / 2.0) + left;
+      }
+      const double t1 = (valid - 1) / a.scale_max, t2 = ca * t1 + cb;
+      double c4[4] = {0, 0, 0, 0};
+      int f_any = 0, s_any = 0, c_any = 0;
+      for (int j = tid; j < N; j += blockDim.x) {
+        const double f = fv[j], s = sv[j];
+        const bool fa = f > t1, sa = s > t2;
+        f_any |= fa; s_any |= sa;
+        if (f >= t1) c4[0] += f;
+        if (s >= t2) c4[1] += s;
+        if (fa && sa) { c4[2] += f; c4[3] += s; c_any = 1; }
+      }
+      block_sum_vec_all<4>(c4, vec);
+      const int FA = block_max_i32(f_any, red_i), SA = block_max_i32(s_any, red_i), CA = block_max_i32(c_any, red_i);
+      if (tid == 0) {
+        const double d1 = FA ? c4[0] : 0.0, d2 = SA ? c4[1] : 0.0;
+        out[a.col_costes] = CA ? c4[2] / d1 : 0.0;
+        out[a.col_costes + 1] = CA ? c4[3] / d2 : 0.0;
+      }
+    }
+    (void)red_d;
+    __syncthreads();
+  }
+}
+
+extern "C" int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
+                                    int F, int C, int Y, int X, int ch0, int ch1,
+                                    const aliby_object* table_dev, int n_obj, int max_area,
+                                    double* out, int ld, int col_pearson, int col_manders, int col_rwc,
+                                    int col_costes, double thr_percent, double costes_scale_max,
+                                    void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (n_obj == 0) return ALIBY_OK;
+  ARG_CHECK(labels && planes && table_dev && out, "NULL argument");
+  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
+  ARG_CHECK(ch0 >= 0 && ch0 < C && ch1 >= 0 && ch1 < C, "channel out of range");
+  ARG_CHECK(F > 0 && Y > 0 && X > 0 && max_area >= 0, "bad shape");
+  const int cols[4] = {col_pearson, col_manders, col_rwc, col_costes};
+  for (int k = 0; k < 4; ++k) ARG_CHECK(cols[k] < 0 || cols[k] + 2 <= ld, "columns exceed row stride");
+  ColocArgs a;
+  a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.ch0 = ch0; a.ch1 = ch1;
+  a.tab = table_dev; a.n_obj = n_obj; a.out = out; a.ld = ld;
+  a.col_pearson = col_pearson; a.col_manders = col_manders; a.col_rwc = col_rwc; a.col_costes = col_costes;
+  a.thr = thr_percent; a.scale_max = costes_scale_max;
+  int cap = 64;
+  while (cap < max_area) cap <<= 1;
+  a.cap = cap;
+  hipStream_t s = as_stream(stream);
+  const size_t need = (size_t)cap * 20;
+  if (need <= 96 * 1024) {
+    a.gscratch = nullptr;
+    dim3 grid(n_obj), block(256);
+    if (dtype == ALIBY_U16) {
+      if (need > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_coloc<u16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_coloc<u16, false>), grid, block, need, s, a);
+    } else {
+      if (need > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_coloc<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_coloc<float, false>), grid, block, need, s, a);
+    }
+  } else {
+    const int g = n_obj < 512 ? n_obj : 512;
+    int rc = aliby_ensure_scratch(ctx, (size_t)g * need);
+    if (rc) return rc;
+    a.gscratch = (unsigned char*)ctx->scratch;
+    dim3 grid(g), block(256);
+    if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_coloc<u16, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_coloc<float, true>), grid, block, 0, s, a);
+  }
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}

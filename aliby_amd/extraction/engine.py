@@ -184,3 +184,16 @@ class FeatureEngine:
             )
           )
         return 2
+
+    def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
+        """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
+        F, Cn, Y, X = planes.shape
+        c = lambda k: -1 if cols.get(k) is None else int(cols[k])  # noqa: E731
+        with self.timed("coloc"):
+            _lib.check(
+                self.lib.aliby_features_coloc(
+                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch0), int(ch1),
+                    _ptr(table.dev), table.n_obj, table.max_area, _ptr(out), out.stride(0), c("pearson"),
+                    c("manders_fold"), c("rwc"), c("costes"), float(thr), float(scale_max), _stream_ptr(),
+                )
+            )

@@ -76,7 +76,7 @@ MONO = {
     "sizeshape": dict(names=lambda kw: feat.sizeshape_names(), launch=_launch_sizeshape, needs_pixels=False),
     "feret": dict(names=lambda kw: feat.feret_names(), launch=_launch_feret, needs_pixels=False),
 }
-MULTI = {}
+MULTI = {name: dict(names=(lambda kw, _n=name: list(feat.COLOC[_n]))) for name in feat.COLOC}
 
 
 def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=False):
@@ -95,17 +95,29 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
         col += 1 if names is None else len(names)
     out = eng.new_output(table.n_obj, col)
     cache = PlaneCache(eng, planes) if planes is not None else None
-    for inst, reg, kw, col0 in specs:
-        if multi:
-            (ch0, ch1), red_ch, red_z = inst[0], inst[1], inst[2]
-            if red_ch == "None":
-                plane, dt = cache.get(red_z)
-                reg["launch"](eng, labels, table, plane, dt, (ch0, ch1), out, col0, kw)
-            else:
+    if multi:
+        # one launch per (pair, red_z): every requested colocalisation metric of that pair together
+        groups = {}
+        for inst, reg, kw, col0 in specs:
+            (ch0, ch1), red_ch, red_z, metric = inst[0], inst[1], inst[2], inst[3]
+            if red_ch != "None":
                 raise NotImplementedError(
                     "channel-combining multi instructions (extract.py:227-235) are not built; "
                     "the builder only emits red_ch='None' (pipe_builder.py:33-43)"
                 )
+            g = groups.setdefault(((ch0, ch1), red_z), dict(cols={}, thr=15.0, scale_max=255.0))
+            g["cols"][metric] = col0
+            if "thr" in kw:
+                g["thr"] = kw["thr"]
+            if "scale_max" in kw:
+                g["scale_max"] = kw["scale_max"]
+        for ((ch0, ch1), red_z), g in groups.items():
+            plane, dt = cache.get(red_z)
+            eng.coloc(labels, plane, dt, ch0, ch1, table, out, g["cols"], thr=g["thr"], scale_max=g["scale_max"])
+        return out, blocks
+    for inst, reg, kw, col0 in specs:
+        if False:
+            pass
         else:
             ch, red_z = inst[0], inst[1]
             if ch == "None" or not reg["needs_pixels"]:

@@ -136,6 +136,17 @@ int aliby_features_feret(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, i
                          const aliby_object* table_dev, int n_obj, int max_h, double* out, int ld,
                          int col0, void* stream);
 
+/* ---- a14: cp_measure colocalisation -------------------------------------- */
+/* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
+ * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the
+ * channel pair (ch0, ch1); col_* is the first of the metric's two columns or -1 to skip it.
+ * thr_percent = 15 and costes_scale_max = 255 are CellProfiler's defaults. */
+int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
+                         int F, int C, int Y, int X, int ch0, int ch1,
+                         const aliby_object* table_dev, int n_obj, int max_area,
+                         double* out, int ld, int col_pearson, int col_manders, int col_rwc,
+                         int col_costes, double thr_percent, double costes_scale_max, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,3 +430,172 @@ def get_core_measurements():
         "sizeshape": get_sizeshape,
         "feret": get_feret,
     }
+
+
+# --------------------------------------------------------------------------------------
+# colocalisation  (CellProfiler MeasureColocalization, per-object branch)
+# call convention of wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask)
+# --------------------------------------------------------------------------------------
+
+
+def _masked(pixels_1, pixels_2, masks):
+    labels = np.asarray(masks).astype(np.int32)
+    m = labels > 0
+    n = int(labels.max()) if labels.size else 0
+    lrange = np.arange(n, dtype=np.int32) + 1
+    # float64 throughout: CellProfiler images are floats; integer inputs must not wrap
+    return labels[m], np.asarray(pixels_1)[m].astype(np.float64), np.asarray(pixels_2)[m].astype(np.float64), lrange
+
+
+def get_correlation_pearson(pixels_1, pixels_2, masks):
+    labels, fi, si, lrange = _masked(pixels_1, pixels_2, masks)
+    n = len(lrange)
+    corr, slope = np.full(n, np.nan), np.full(n, np.nan)
+    if n and len(labels):
+        mean1 = _fix(ndi.mean(fi, labels, lrange))
+        mean2 = _fix(ndi.mean(si, labels, lrange))
+        x = fi - mean1[labels - 1]
+        y = si - mean2[labels - 1]
+        sxx = _fix(ndi.sum(x * x, labels, lrange))
+        syy = _fix(ndi.sum(y * y, labels, lrange))
+        sxy = _fix(ndi.sum(x * y, labels, lrange))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            corr = sxy / (np.sqrt(sxx) * np.sqrt(syy))
+            slope = sxy / sxx  # least-squares A of  A*i1 + B = i2
+        cnt = _fix(ndi.sum(np.ones_like(fi), labels, lrange))
+        corr[cnt == 0] = np.nan
+        slope[cnt == 0] = np.nan
+    return {"Correlation_Pearson": corr, "Correlation_Slope": slope}
+
+
+def _threshold_sums(labels, fi, si, lrange, thr):
+    tff = (thr / 100) * _fix(ndi.maximum(fi, labels, lrange))
+    tss = (thr / 100) * _fix(ndi.maximum(si, labels, lrange))
+    a1 = fi >= tff[labels - 1]
+    a2 = si >= tss[labels - 1]
+    combined = a1 & a2
+    tot_fi = _fix(ndi.sum(fi[a1], labels[a1], lrange))
+    tot_si = _fix(ndi.sum(si[a2], labels[a2], lrange))
+    return combined, tot_fi, tot_si
+
+
+def get_correlation_manders_fold(pixels_1, pixels_2, masks, thr=15):
+    labels, fi, si, lrange = _masked(pixels_1, pixels_2, masks)
+    n = len(lrange)
+    M1, M2 = np.zeros(n), np.zeros(n)
+    if n and len(labels):
+        combined, tot_fi, tot_si = _threshold_sums(labels, fi, si, lrange, thr)
+        if combined.any():
+            with np.errstate(invalid="ignore", divide="ignore"):
+                M1 = _fix(ndi.sum(fi[combined], labels[combined], lrange)) / tot_fi
+                M2 = _fix(ndi.sum(si[combined], labels[combined], lrange)) / tot_si
+    return {"Correlation_Manders_1": M1, "Correlation_Manders_2": M2}
+
+
+def get_correlation_rwc(pixels_1, pixels_2, masks, thr=15):
+    labels, fi, si, lrange = _masked(pixels_1, pixels_2, masks)
+    n = len(lrange)
+    R1, R2 = np.zeros(n), np.zeros(n)
+    if n and len(labels):
+        combined, tot_fi, tot_si = _threshold_sums(labels, fi, si, lrange, thr)
+        rank1 = np.lexsort((labels, fi))
+        rank2 = np.lexsort((labels, si))
+        u1 = np.hstack([[False], fi[rank1[:-1]] != fi[rank1[1:]]])
+        u2 = np.hstack([[False], si[rank2[:-1]] != si[rank2[1:]]])
+        s1, s2 = np.cumsum(u1), np.cumsum(u2)
+        im1 = np.zeros(fi.shape, dtype=int)
+        im2 = np.zeros(si.shape, dtype=int)
+        im1[rank1] = s1
+        im2[rank2] = s2
+        R = max(im1.max(), im2.max()) + 1
+        weight = (R - np.abs(im1 - im2)) * 1.0 / R
+        if combined.any():
+            w = weight[combined]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                R1 = _fix(ndi.sum(fi[combined] * w, labels[combined], lrange)) / tot_fi
+                R2 = _fix(ndi.sum(si[combined] * w, labels[combined], lrange)) / tot_si
+    return {"Correlation_RWC_1": R1, "Correlation_RWC_2": R2}
+
+
+def _pearsonr(x, y):
+    """scipy.stats.pearsonr's statistic; nan for constant input (no ValueError)."""
+    xm, ym = x - x.mean(), y - y.mean()
+    nx, ny = np.sqrt((xm * xm).sum()), np.sqrt((ym * ym).sum())
+    if nx == 0 or ny == 0:
+        return np.nan
+    return max(min(float((xm / nx) @ (ym / ny)), 1.0), -1.0)
+
+
+def bisection_costes(fi, si, scale_max=255):
+    """CellProfiler MeasureColocalization.bisection_costes ("Faster" mode)."""
+    non_zero = (fi > 0) | (si > 0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        xvar = np.var(fi[non_zero], ddof=1)
+        yvar = np.var(si[non_zero], ddof=1)
+        xmean = np.mean(fi[non_zero])
+        ymean = np.mean(si[non_zero])
+        zvar = np.var(fi[non_zero] + si[non_zero], ddof=1)
+        covar = 0.5 * (zvar - (xvar + yvar))
+        denom = 2 * covar
+        num = (yvar - xvar) + np.sqrt((yvar - xvar) * (yvar - xvar) + 4 * (covar * covar))
+        a = num / denom
+        b = ymean - a * xmean
+    left, right = 1, scale_max
+    mid = ((right - left) // (6 / 5)) + left
+    lastmid = 0
+    valid = 1
+    while lastmid != mid:
+        thr_fi_c = mid / scale_max
+        thr_si_c = (a * thr_fi_c) + b
+        combt = (fi < thr_fi_c) | (si < thr_si_c)
+        if np.count_nonzero(combt) <= 2:
+            left = mid - 1
+        else:
+            cost = _pearsonr(fi[combt], si[combt])
+            if cost < 0:
+                left = mid - 1
+            elif cost >= 0:
+                right = mid + 1
+                valid = mid
+        lastmid = mid
+        if right - left > 6:
+            mid = ((right - left) // (6 / 5)) + left
+        else:
+            mid = ((right - left) // 2) + left
+    thr_fi_c = (valid - 1) / scale_max
+    thr_si_c = (a * thr_fi_c) + b
+    return thr_fi_c, thr_si_c
+
+
+def get_correlation_costes(pixels_1, pixels_2, masks, scale_max=255):
+    """Costes' automatic threshold (bisection) then Manders-style fractions above it.
+    As called by the reference there is one object per mask, so the "whole image" threshold of
+    CellProfiler is that object's own threshold; for multi-label masks it is evaluated per label."""
+    labels, fi, si, lrange = _masked(pixels_1, pixels_2, masks)
+    n = len(lrange)
+    C1, C2 = np.zeros(n), np.zeros(n)
+    for i, lab in enumerate(lrange):
+        sel = labels == lab
+        if not sel.any():
+            continue
+        f, s = fi[sel], si[sel]
+        t1, t2 = bisection_costes(f, s, scale_max)
+        a1, a2 = f > t1, s > t2
+        comb = a1 & a2
+        tot1 = f[f >= t1].sum() if a1.any() else 0.0
+        tot2 = s[s >= t2].sum() if a2.any() else 0.0
+        if comb.any():
+            with np.errstate(invalid="ignore", divide="ignore"):
+                C1[i] = np.float64(f[comb].sum()) / np.float64(tot1)
+                C2[i] = np.float64(s[comb].sum()) / np.float64(tot2)
+    return {"Correlation_Costes_1": C1, "Correlation_Costes_2": C2}
+
+
+def get_correlation_measurements():
+    """cp_measure.bulk.get_correlation_measurements() restated: name -> f(pixels_1, pixels_2, masks, **kw)."""
+    return {
+        "pearson": get_correlation_pearson,
+        "manders_fold": get_correlation_manders_fold,
+        "rwc": get_correlation_rwc,
+        "costes": get_correlation_costes,
+    }
