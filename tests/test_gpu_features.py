@@ -85,3 +85,33 @@ def test_sizeshape_matches_oracle(engine, objset):
     _compare(names, out.cpu().numpy(), ref,
              exact=("Area", "BoundingBoxArea", "BoundingBoxMaximum_X", "BoundingBoxMaximum_Y", "BoundingBoxMinimum_X",
                     "BoundingBoxMinimum_Y", "EulerNumber", "ConvexArea"))
+
+
+@pytest.mark.parametrize("objset", ["nuclei", "cells"])
+@pytest.mark.parametrize("mode", ["u16", "f32_unit"])
+def test_coloc_matches_oracle(engine, objset, mode):
+    """pearson / manders_fold / rwc / costes for every channel pair of a 3-channel FOV."""
+    import torch
+    from itertools import combinations
+    from oracle import cp_measure_restated as cpm
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+
+    f = synth.make_fov(1, 1, shape=(320, 320), n_channels=3, n_target=30)
+    labels = f[objset]
+    planes = f["pixels"][:, 0]
+    if mode == "f32_unit":  # CellProfiler-style [0,1] floats: exercises the Costes bisection properly
+        planes = (planes.astype(np.float32) / np.float32(65535.0)).astype(np.float32)
+    dl = to_device_u16(labels[None])
+    dp, dt = to_device_planes(planes[None])
+    tab = engine.object_table(dl)
+    for c0, c1 in combinations(range(3), 2):
+        out = engine.new_output(tab.n_obj, 8)
+        engine.coloc(dl, dp, dt, c0, c1, tab, out, dict(pearson=0, manders_fold=2, rwc=4, costes=6))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        ref = {}
+        for fn in cpm.get_correlation_measurements().values():
+            ref.update(fn(planes[c0], planes[c1], labels))
+        names = ["Correlation_Pearson", "Correlation_Slope", "Correlation_Manders_1", "Correlation_Manders_2",
+                 "Correlation_RWC_1", "Correlation_RWC_2", "Correlation_Costes_1", "Correlation_Costes_2"]
+        _compare(names, got, ref)
