@@ -185,6 +185,33 @@ class FeatureEngine:
           )
         return 2
 
+    def mec(self, labels, table: ObjectTable) -> torch.Tensor:
+        """Minimum enclosing circles [n_obj,4], computed once per object table."""
+        cached = getattr(table, "_mec", None)
+        if cached is not None:
+            return cached
+        F, Y, X = labels.shape
+        mec = torch.empty((max(table.n_obj, 1), 4), dtype=torch.float64, device=labels.device)
+        with self.timed("mec"):
+            _lib.check(self.lib.aliby_object_mec(self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj,
+                                                 table.max_h, _ptr(mec), _stream_ptr()))
+        table._mec = mec
+        return mec
+
+    def zernike(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, weighted: bool):
+        F, Y, X = labels.shape
+        Cn = planes.shape[1] if planes is not None else 0
+        mec = self.mec(labels, table)
+        with self.timed("radial_zernikes" if weighted else "zernike"):
+            _lib.check(
+                self.lib.aliby_features_zernike(
+                    self.ctx.handle, _ptr(labels), _ptr(planes) if weighted else 0, dtype if weighted else 0, F, Cn, Y, X,
+                    int(channel) if weighted else 0, _ptr(table.dev), table.n_obj, _ptr(mec), 1 if weighted else 0,
+                    _ptr(out), out.stride(0), col0, _stream_ptr(),
+                )
+            )
+        return 60 if weighted else 30
+
     def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
         """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
         F, Cn, Y, X = planes.shape

@@ -43,18 +43,13 @@ class PlaneCache:
             dt = self.dtype if op == _lib.RED_MAX else _lib.F32
             out = torch.empty((F, C, Y, X), dtype=torch.uint16 if dt == _lib.U16 else torch.float32,
                               device=self.tensor.device)
-            _lib.check(
-                self.eng.lib.aliby_reduce_z(self.eng.ctx.handle, _ptr(self.tensor), self.dtype, F * C, Z, Y * X, op,
-                                            _ptr(out), dt, _stream_ptr())
-            )
+            with self.eng.timed("reduce_z"):
+                _lib.check(
+                    self.eng.lib.aliby_reduce_z(self.eng.ctx.handle, _ptr(self.tensor), self.dtype, F * C, Z, Y * X,
+                                                op, _ptr(out), dt, _stream_ptr())
+                )
         self._cache[red_z] = (out, dt)
         return out, dt
-
-
-def _mono_columns(metric, kw):
-    if metric in MONO:
-        return MONO[metric]["names"](kw)
-    raise KeyError(metric)
 
 
 def _launch_intensity(eng, labels, table, plane, dt, ch, out, col0, kw):
@@ -69,36 +64,68 @@ def _launch_feret(eng, labels, table, plane, dt, ch, out, col0, kw):
     eng.feret(labels, table, out, col0)
 
 
+def _launch_zernike(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.zernike(labels, None, 0, 0, table, out, col0, weighted=False)
+
+
+def _launch_radial_zernikes(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.zernike(labels, plane, dt, ch, table, out, col0, weighted=True)
+
+
+def _launch_texture(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.texture(labels, plane, dt, ch, table, out, col0, scale=kw.get("scale", 3), gray_levels=kw.get("gray_levels", 256))
+
+
+def _launch_radial_distribution(eng, labels, table, plane, dt, ch, out, col0, kw):
+    eng.radial_distribution(labels, plane, dt, ch, table, out, col0, bin_count=kw.get("bin_count", 4),
+                            scaled=kw.get("scaled", True), maximum_radius=kw.get("maximum_radius", 100))
+
+
 # name -> {names(kw) -> list[str] | None (scalar), launch, needs_pixels}
 MONO = {
     "intensity": dict(names=lambda kw: feat.intensity_names(kw.get("edge_measurements", True)),
                       launch=_launch_intensity, needs_pixels=True),
     "sizeshape": dict(names=lambda kw: feat.sizeshape_names(), launch=_launch_sizeshape, needs_pixels=False),
     "feret": dict(names=lambda kw: feat.feret_names(), launch=_launch_feret, needs_pixels=False),
+    "zernike": dict(names=lambda kw: feat.zernike_names(), launch=_launch_zernike, needs_pixels=False),
+    "radial_zernikes": dict(names=lambda kw: feat.radial_zernike_names(), launch=_launch_radial_zernikes,
+                            needs_pixels=True),
 }
 MULTI = {name: dict(names=(lambda kw, _n=name: list(feat.COLOC[_n]))) for name in feat.COLOC}
 
 
+def register_optional(eng_cls):
+    """Families whose kernels are built in later commits register themselves when the engine has them."""
+    if hasattr(eng_cls, "texture"):
+        MONO["texture"] = dict(names=lambda kw: feat.texture_names(kw.get("scale", 3), kw.get("gray_levels", 256)),
+                               launch=_launch_texture, needs_pixels=True)
+    if hasattr(eng_cls, "radial_distribution"):
+        MONO["radial_distribution"] = dict(names=lambda kw: feat.radial_distribution_names(kw.get("bin_count", 4)),
+                                           launch=_launch_radial_distribution, needs_pixels=True)
+
+
 def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=False):
     """Run every instruction over every object; returns (matrix [n_obj, n_cols] on device, blocks)."""
+    register_optional(type(eng))
     blocks, specs = [], []
     col = 0
     for inst in instructions:
         metric = inst[-1]
         kw = dict(cp_measure_kwargs.get(metric, {}))
-        reg = (MULTI if multi and inst[1] == "None" else MONO)
+        reg = MULTI if (multi and inst[1] == "None") else MONO
         if metric not in reg:
             raise KeyError(metric)
         names = reg[metric]["names"](kw)
         blocks.append((col, names))
-        specs.append((inst, reg[metric], kw, col))
+        specs.append((inst, reg[metric], kw, col, 1 if names is None else len(names)))
         col += 1 if names is None else len(names)
     out = eng.new_output(table.n_obj, col)
     cache = PlaneCache(eng, planes) if planes is not None else None
+
     if multi:
         # one launch per (pair, red_z): every requested colocalisation metric of that pair together
         groups = {}
-        for inst, reg, kw, col0 in specs:
+        for inst, reg, kw, col0, _ in specs:
             (ch0, ch1), red_ch, red_z, metric = inst[0], inst[1], inst[2], inst[3]
             if red_ch != "None":
                 raise NotImplementedError(
@@ -107,26 +134,31 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
                 )
             g = groups.setdefault(((ch0, ch1), red_z), dict(cols={}, thr=15.0, scale_max=255.0))
             g["cols"][metric] = col0
-            if "thr" in kw:
-                g["thr"] = kw["thr"]
-            if "scale_max" in kw:
-                g["scale_max"] = kw["scale_max"]
+            g["thr"] = kw.get("thr", g["thr"])
+            g["scale_max"] = kw.get("scale_max", g["scale_max"])
+        if cache is None:
+            raise Exception("pixels are required for colocalisation instructions")
         for ((ch0, ch1), red_z), g in groups.items():
             plane, dt = cache.get(red_z)
             eng.coloc(labels, plane, dt, ch0, ch1, table, out, g["cols"], thr=g["thr"], scale_max=g["scale_max"])
         return out, blocks
-    for inst, reg, kw, col0 in specs:
-        if False:
-            pass
-        else:
-            ch, red_z = inst[0], inst[1]
-            if ch == "None" or not reg["needs_pixels"]:
-                if ch != "None" and cache is not None:
-                    cache.get(red_z)  # the reference would still reduce (and raise on a bad reducer)
-                reg["launch"](eng, labels, table, None, 0, None, out, col0, kw)
+
+    done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
+    for inst, reg, kw, col0, ncols in specs:
+        ch, red_z, metric = inst[0], inst[1], inst[-1]
+        if ch == "None" or not reg["needs_pixels"]:
+            if ch != "None" and cache is not None:
+                cache.get(red_z)  # the reference would still reduce (and raise on a bad reducer)
+            key = (metric, tuple(sorted(kw.items())))
+            if key in done:
+                # e.g. "feret"/"zernike" listed under every channel: same labels, same numbers
+                out[:, col0 : col0 + ncols] = out[:, done[key] : done[key] + ncols]
             else:
-                if cache is None:
-                    raise Exception("pixels are required for this instruction")
-                plane, dt = cache.get(red_z)
-                reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw)
+                reg["launch"](eng, labels, table, None, 0, None, out, col0, kw)
+                done[key] = col0
+        else:
+            if cache is None:
+                raise Exception("pixels are required for this instruction")
+            plane, dt = cache.get(red_z)
+            reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw)
     return out, blocks

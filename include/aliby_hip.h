@@ -136,6 +136,19 @@ int aliby_features_feret(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, i
                          const aliby_object* table_dev, int n_obj, int max_h, double* out, int ld,
                          int col0, void* stream);
 
+/* Minimum enclosing circle of each object's pixel centres (centrosome.cpmorphology.
+ * minimum_enclosing_circle, used by the Zernike families): mec_dev[n_obj][4] = (centre_i, centre_j,
+ * radius, n_hull_vertices) in tile coordinates. */
+int aliby_object_mec(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                     const aliby_object* table_dev, int n_obj, int max_h, double* mec_dev, void* stream);
+
+/* cp_measure "zernike" (weighted=0: 30 columns, |sum Z_nm|/(pi r^2)) and "radial_zernikes"
+ * (weighted=1: 30 magnitudes |sum I Z_nm|/n_pixels then 30 phases atan2(Re,Im)); n<=9. */
+int aliby_features_zernike(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
+                           int F, int C, int Y, int X, int channel, const aliby_object* table_dev,
+                           int n_obj, const double* mec_dev, int weighted, double* out, int ld, int col0,
+                           void* stream);
+
 /* ---- a14: cp_measure colocalisation -------------------------------------- */
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the

@@ -109,9 +109,57 @@ def test_coloc_matches_oracle(engine, objset, mode):
         engine.coloc(dl, dp, dt, c0, c1, tab, out, dict(pearson=0, manders_fold=2, rwc=4, costes=6))
         torch.cuda.synchronize()
         got = out.cpu().numpy()
+        # the reference evaluates one full-frame binary mask per object (extract.py:222-226); RWC's
+        # ranks and Costes' threshold are per call, so the oracle is driven the same way
         ref = {}
-        for fn in cpm.get_correlation_measurements().values():
-            ref.update(fn(planes[c0], planes[c1], labels))
+        for lab in range(1, int(labels.max()) + 1):
+            one = (labels == lab).astype(np.uint16)
+            for fn in cpm.get_correlation_measurements().values():
+                for k, v in fn(planes[c0], planes[c1], one).items():
+                    ref.setdefault(k, []).append(v[0])
         names = ["Correlation_Pearson", "Correlation_Slope", "Correlation_Manders_1", "Correlation_Manders_2",
                  "Correlation_RWC_1", "Correlation_RWC_2", "Correlation_Costes_1", "Correlation_Costes_2"]
         _compare(names, got, ref)
+
+
+@pytest.mark.parametrize("objset", ["nuclei", "cells"])
+def test_zernike_and_mec_match_oracle(engine, objset):
+    import torch
+    from oracle import zernike_restated as zr
+    from aliby_amd.extraction import features as feat
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+
+    f = synth.make_fov(1, 2, shape=(300, 340), n_target=30)
+    labels = f[objset]
+    planes = f["pixels"][:, 0]
+    dl = to_device_u16(labels[None])
+    dp, dt = to_device_planes(planes[None])
+    tab = engine.object_table(dl)
+    mec = engine.mec(dl, tab).cpu().numpy()
+    centres, radii = zr.minimum_enclosing_circle(labels)
+    assert np.allclose(mec[:, 2], radii, rtol=1e-9), (mec[:3], radii[:3])
+    assert np.allclose(mec[:, :2], centres, rtol=1e-9, atol=1e-9)
+    # shape Zernikes
+    names = feat.zernike_names()
+    out = engine.new_output(tab.n_obj, 30)
+    engine.zernike(dl, None, 0, 0, tab, out, 0, weighted=False)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ref = zr.get_zernike(labels)
+    for j, n in enumerate(names):
+        assert np.allclose(got[:, j], ref[n], rtol=RTOL, atol=1e-7), (n, got[:3, j], ref[n][:3])
+    # intensity-weighted Zernikes: magnitudes then phases
+    names = feat.radial_zernike_names()
+    for ch in range(planes.shape[0]):
+        out = engine.new_output(tab.n_obj, 60)
+        engine.zernike(dl, dp, dt, ch, tab, out, 0, weighted=True)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        ref = zr.get_radial_zernikes(labels, planes[ch])
+        scale = np.abs(ref[names[0]])  # Z_00 magnitude = mean intensity inside the disc
+        for j in range(30):
+            assert np.allclose(got[:, j], ref[names[j]], rtol=RTOL, atol=1e-7 * scale.max()), names[j]
+            mag = ref[names[j]]
+            dphi = np.angle(np.exp(1j * (got[:, 30 + j] - ref[names[30 + j]])))
+            ok = (np.abs(dphi) < 1e-4) | (mag < 1e-6 * scale)
+            assert ok.all(), (names[30 + j], got[~ok, 30 + j], ref[names[30 + j]][~ok])
