@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void k_zernike(ZernikeArgs a) {
       const double r2 = x * x + y * y;
       double wgt = 1.0;
       if (WEIGHTED) wgt = (double)px_load<T>(px, idx);
-      if (r2 > 1.0) continue;  // the radial polynomial is zeroed outside the unit disc
+      // zero outside the unit disc.  The 2-3 pixels that DEFINE the enclosing circle sit at r2 = 1 +- 1ulp;
+      // a 1e-9 guard band makes their membership independent of rounding (same rule in the oracle).
+      if (r2 > 1.0 + 1e-9) continue;
       // m outer (running power of z = y + i x), n inner: every index below is a compile-time constant
       double zr = 1.0, zi = 0.0;
 #pragma unroll

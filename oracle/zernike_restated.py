@@ -49,7 +49,9 @@ def construct_zernike_polynomials(x, y, zernike_indexes, weight=None):
         for k in range((n - m) // 2 + 1):
             s *= r_square
             s += lut[idx, k]
-        s[r_square > 1] = 0
+        # pixels defining the enclosing circle sit at r^2 = 1 +- 1ulp: a 1e-9 guard band keeps their
+        # membership independent of rounding (centrosome itself tests r_square > 1 on its own rounding)
+        s[r_square > 1 + 1e-9] = 0
         if weight is not None:
             s = s * weight.astype(s.dtype)
         zf[idx] = s if m == 0 else s * (z**m)
