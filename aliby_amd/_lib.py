@@ -70,6 +70,7 @@ _SIGNATURES = {
     "aliby_features_feret": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "aliby_object_mec": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "aliby_features_zernike": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "aliby_features_texture": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_coloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i,
                                   C.c_double, C.c_double, _vp]),
 }

@@ -1,0 +1,274 @@
+// feat_texture.hip — cp_measure "texture" (Haralick), one workgroup per (object, channel).
+//
+// Reference call site: wrap_cp_measure_features (extraction/core/functions/loaders.py:135-150) with
+// fun = get_core_measurements()["texture"] (default feature list, pipe_builder.py:49-56).
+// cp_measure 0.1.17 / mahotas 1.4.18 are not vendored; restated from CellProfiler's MeasureTexture
+// and mahotas.features.haralick(distance=scale, ignore_zeros=True):
+//   grey level = uint16 >> 8 (skimage img_as_ubyte) or rint(255 f) for [0,1] floats;
+//   per object: bbox crop, non-object pixels = 0; symmetric co-occurrence at distance `scale` for the
+//   directions (0,1),(1,1),(1,0),(1,-1); pairs touching grey level 0 are dropped; 13 statistics.
+//
+// MI355X shape: a 256x256 co-occurrence matrix does not fit LDS in any useful way and is >99% empty for
+// a ~1k-pixel object, so the matrix is kept SPARSE: the (lo,hi) grey-level pair of every pixel pair is
+// a 16-bit key, keys are bitonic-sorted in LDS, equal-key runs are the non-zero cells.  Marginals
+// (p_x, p_{x+y}, p_{x-y}) are integer LDS histograms, so every statistic is exact-integer counts
+// divided once by the total: no atomics on floats, run-to-run deterministic.
+#include "common.h"
+
+typedef unsigned short u16;
+
+#define TX_NSTAT 13
+
+struct TextureArgs {
+  const u16* labels;
+  const void* planes;
+  int F, C, Y, X, channel;
+  const aliby_object* tab;
+  int n_obj;
+  int cap_pix;   // >= max bbox area (bytes for the grey crop), multiple of 16
+  int cap_keys;  // power of two >= max area
+  unsigned char* gscratch;
+  int scale, gray_levels;
+  double* out;
+  int ld, col0;
+};
+
+__device__ __forceinline__ int grey_of(unsigned short v, int gl) {
+  int q = v >> 8;
+  if (gl != 256) q = (int)((double)q / 255.0 * (double)(gl - 1));
+  return q;
+}
+__device__ __forceinline__ int grey_of(float v, int gl) {
+  double x = rint((double)v * 255.0);
+  x = fmin(fmax(x, 0.0), 255.0);
+  int q = (int)x;
+  if (gl != 256) q = (int)((double)q / 255.0 * (double)(gl - 1));
+  return q;
+}
+
+__device__ __forceinline__ double plog2p(double p) { return p > 0 ? p * log2(p) : 0.0; }
+
+template <typename T, bool GLOBAL>
+__global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ int hx[256];      // p_x counts
+  __shared__ int hplus[512];   // p_{x+y} counts
+  __shared__ int hminus[256];  // p_{x-y} counts
+  __shared__ double vec[4 * 8];
+  __shared__ int red_i[8];
+  __shared__ int wsum[4];
+
+  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * ((size_t)a.cap_pix + (size_t)a.cap_keys * 4)) : lds_raw;
+  unsigned char* g = ws;
+  unsigned int* keys = reinterpret_cast<unsigned int*>(ws + a.cap_pix);
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+  const int DY[4] = {0, 1, 1, 1}, DX[4] = {1, 1, 0, -1};
+
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    double* out = a.out + (size_t)oi * a.ld + a.col0;
+    if (o.area <= 0) {
+      for (int k = tid; k < 4 * TX_NSTAT; k += blockDim.x) out[k] = NAN;
+      continue;
+    }
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const T* px = reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.channel) * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, npix = h * w;
+    const u16 L = (u16)o.label;
+
+    __syncthreads();
+    int gmax = 0;
+    for (int i = tid; i < npix; i += blockDim.x) {
+      const size_t idx = (size_t)(o.y0 + i / w) * a.X + (o.x0 + i % w);
+      int q = 0;
+      if (lab[idx] == L) q = grey_of(px[idx], a.gray_levels);
+      g[i] = (unsigned char)q;
+      gmax = max(gmax, q);
+    }
+    const int maxv = block_max_i32(gmax, red_i) + 1;  // side of mahotas' matrix: max grey level + 1
+    __syncthreads();
+
+    for (int d = 0; d < 4; ++d) {
+      const int dy = DY[d] * a.scale, dx = DX[d] * a.scale;
+      double* fo = out + d * TX_NSTAT;
+      // ---- pair keys (order-preserving compaction is unnecessary: keys get sorted) ----------
+      for (int k = tid; k < 256; k += blockDim.x) { hx[k] = 0; hminus[k] = 0; }
+      for (int k = tid; k < 512; k += blockDim.x) hplus[k] = 0;
+      int base = 0;
+      for (int i0 = 0; i0 < npix; i0 += blockDim.x) {
+        const int i = i0 + tid;
+        bool ok = false;
+        unsigned int key = 0;
+        if (i < npix) {
+          const int r = i / w, c = i % w, r2 = r + dy, c2 = c + dx;
+          if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
+            const int va = g[i], vb = g[r2 * w + c2];
+            if (va > 0 && vb > 0) {
+              ok = true;
+              key = (unsigned)(min(va, vb) << 8) | (unsigned)max(va, vb);
+            }
+          }
+        }
+        const int pos = block_compact_slot(ok, base, wsum);
+        if (ok) keys[pos] = key;
+      }
+      __syncthreads();
+      const int NP = base;  // ordered pixel pairs; T = 2*NP entries in the symmetric matrix
+      if (NP == 0) {
+        // mahotas raises ValueError on an empty matrix; CellProfiler records NaN
+        for (int k = tid; k < TX_NSTAT; k += blockDim.x) fo[k] = NAN;
+        __syncthreads();
+        continue;
+      }
+      const int n2 = next_pow2(NP);
+      for (int i = NP + tid; i < n2; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
+      block_bitonic_sort(keys, n2);
+      const double Tt = 2.0 * (double)NP;
+
+      // ---- runs -> cells: integer marginals + cell sums ------------------------------------------
+      double acc[3] = {0, 0, 0};  // sum p^2 (as counts^2), sum i*j*count, sum p*log2(p)
+      for (int i = tid; i < NP; i += blockDim.x) {
+        const unsigned int key = keys[i];
+        if (i > 0 && keys[i - 1] == key) continue;
+        int lo_ = i + 1, hi_ = NP;
+        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
+        const int c = lo_ - i;                       // pairs with this unordered grey-level pair
+        const int lo = (int)(key >> 8), hi = (int)(key & 255u);
+        if (lo == hi) {
+          atomicAdd(&hx[lo], 2 * c);
+          const double p = 2.0 * c / Tt;
+          acc[0] += 4.0 * (double)c * (double)c;
+          acc[2] += plog2p(p);
+        } else {
+          atomicAdd(&hx[lo], c);
+          atomicAdd(&hx[hi], c);
+          const double p = (double)c / Tt;
+          acc[0] += 2.0 * (double)c * (double)c;
+          acc[2] += 2.0 * plog2p(p);
+        }
+        atomicAdd(&hplus[lo + hi], 2 * c);
+        atomicAdd(&hminus[hi - lo], 2 * c);
+        acc[1] += 2.0 * (double)c * (double)lo * (double)hi;
+      }
+      block_sum_vec_all<3>(acc, vec);
+      __syncthreads();
+      const double f_asm = acc[0] / (Tt * Tt);
+      const double sum_ij = acc[1] / Tt;
+      const double f_entropy = -acc[2];
+
+      // ---- marginal statistics --------------------------------------------------------------------
+      double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      // m0 = ux, m1 = sum k^2 px, m2 = HX(sum p log p), m3 = contrast, m4 = IDM, m5 = sum p_minus,
+      // m6 = sum p_minus^2 (for the vector variance), m7 = difference entropy (sum p log p)
+      for (int k = tid; k < 256; k += blockDim.x) {
+        const double pxk = (double)hx[k] / Tt;
+        m[0] += (double)k * pxk;
+        m[1] += (double)k * (double)k * pxk;
+        m[2] += plog2p(pxk);
+        const double pm = (double)hminus[k] / Tt;
+        m[3] += (double)k * (double)k * pm;
+        m[4] += pm / (1.0 + (double)k * (double)k);
+        if (k < maxv) { m[5] += pm; m[6] += pm * pm; }
+        m[7] += plog2p(pm);
+      }
+      block_sum_vec_all<8>(m, vec);
+      double s[3] = {0, 0, 0};  // sum average, sum k^2 p_plus, sum entropy (sum p log p)
+      for (int k = tid; k < 512; k += blockDim.x) {
+        const double pp = (double)hplus[k] / Tt;
+        s[0] += (double)k * pp;
+        s[1] += (double)k * (double)k * pp;
+        s[2] += plog2p(pp);
+      }
+      block_sum_vec_all<3>(s, vec);
+
+      // HXY1 = -sum_ij p_ij log2(px_i py_j): second pass over the cells now that p_x is complete
+      double hxy = 0;
+      for (int i = tid; i < NP; i += blockDim.x) {
+        const unsigned int key = keys[i];
+        if (i > 0 && keys[i - 1] == key) continue;
+        int lo_ = i + 1, hi_ = NP;
+        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
+        const int c = lo_ - i;
+        const int lo = (int)(key >> 8), hi = (int)(key & 255u);
+        const double pl = (double)hx[lo] / Tt, ph = (double)hx[hi] / Tt;
+        hxy += (2.0 * (double)c / Tt) * log2(pl * ph);
+      }
+      double hv[1] = {hxy};
+      block_sum_vec_all<1>(hv, vec);
+
+      if (tid == 0) {
+        const double ux = m[0], vx = m[1] - ux * ux, sx = sqrt(vx);
+        const double HX = -m[2];
+        const double HXY1 = -hv[0];
+        const double HXY2 = 2.0 * HX;  // -sum (px_i py_j) log2(px_i py_j) with p symmetric
+        fo[0] = f_asm;
+        fo[1] = m[3];
+        fo[2] = (sx == 0.0) ? 1.0 : (1.0 / sx / sx) * (sum_ij - ux * ux);
+        fo[3] = vx;
+        fo[4] = m[4];
+        fo[5] = s[0];
+        fo[6] = s[1] - s[0] * s[0];
+        fo[7] = -s[2];
+        fo[8] = f_entropy;
+        {
+          // numpy var of the length-maxv vector p_{x-y}: mean(|x - mean|^2)
+          const double mean = m[5] / (double)maxv;
+          fo[9] = m[6] / (double)maxv - mean * mean;
+        }
+        fo[10] = -m[7];
+        fo[11] = (HX == 0.0) ? (f_entropy - HXY1) : (f_entropy - HXY1) / HX;
+        fo[12] = sqrt(fmax(0.0, 1.0 - exp(-2.0 * (HXY2 - f_entropy))));
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
+                                      int F, int C, int Y, int X, int channel,
+                                      const aliby_object* table_dev, int n_obj, int max_h, int max_w,
+                                      int max_area, int scale, int gray_levels, double* out, int ld,
+                                      int col0, void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (n_obj == 0) return ALIBY_OK;
+  ARG_CHECK(labels && planes && table_dev && out, "NULL argument");
+  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
+  ARG_CHECK(channel >= 0 && channel < C, "channel out of range");
+  ARG_CHECK(F > 0 && Y > 0 && X > 0 && max_h >= 0 && max_w >= 0 && max_area >= 0, "bad shape");
+  ARG_CHECK(scale >= 1 && gray_levels >= 2 && gray_levels <= 256, "scale >= 1 and 2 <= gray_levels <= 256");
+  ARG_CHECK(col0 >= 0 && col0 + 4 * TX_NSTAT <= ld, "columns exceed row stride");
+  TextureArgs a;
+  a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.channel = channel;
+  a.tab = table_dev; a.n_obj = n_obj; a.scale = scale; a.gray_levels = gray_levels;
+  a.out = out; a.ld = ld; a.col0 = col0;
+  a.cap_pix = (int)(((size_t)max_h * max_w + 15) & ~(size_t)15);
+  int ck = 64;
+  while (ck < max_area) ck <<= 1;
+  a.cap_keys = ck;
+  const size_t need = (size_t)a.cap_pix + (size_t)ck * 4;
+  hipStream_t s = as_stream(stream);
+  if (need <= 96 * 1024) {
+    a.gscratch = nullptr;
+    dim3 grid(n_obj), block(256);
+    if (dtype == ALIBY_U16) {
+      if (need > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_texture<u16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_texture<u16, false>), grid, block, need, s, a);
+    } else {
+      if (need > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_texture<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_texture<float, false>), grid, block, need, s, a);
+    }
+  } else {
+    const int g = n_obj < 512 ? n_obj : 512;
+    int rc = aliby_ensure_scratch(ctx, (size_t)g * need);
+    if (rc) return rc;
+    a.gscratch = (unsigned char*)ctx->scratch;
+    dim3 grid(g), block(256);
+    if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_texture<u16, false ? false : true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_texture<float, true>), grid, block, 0, s, a);
+  }
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}

@@ -212,6 +212,18 @@ class FeatureEngine:
             )
         return 60 if weighted else 30
 
+    def texture(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, scale=3, gray_levels=256):
+        F, Cn, Y, X = planes.shape
+        with self.timed("texture"):
+            _lib.check(
+                self.lib.aliby_features_texture(
+                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel), _ptr(table.dev),
+                    table.n_obj, table.max_h, table.max_w, table.max_area, int(scale), int(gray_levels), _ptr(out),
+                    out.stride(0), col0, _stream_ptr(),
+                )
+            )
+        return 52
+
     def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
         """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
         F, Cn, Y, X = planes.shape

@@ -149,6 +149,14 @@ int aliby_features_zernike(aliby_ctx* ctx, const uint16_t* labels, const void* p
                            int n_obj, const double* mec_dev, int weighted, double* out, int ld, int col0,
                            void* stream);
 
+/* cp_measure "texture": 13 Haralick statistics x 4 directions (direction-major, 52 columns) of the
+ * object's bbox crop quantised to 8-bit grey levels (uint16 >> 8; [0,1] floats -> rint(255 f)),
+ * co-occurrence distance `scale` (3), zero grey level ignored (mahotas ignore_zeros=True). */
+int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
+                           int F, int C, int Y, int X, int channel, const aliby_object* table_dev,
+                           int n_obj, int max_h, int max_w, int max_area, int scale, int gray_levels,
+                           double* out, int ld, int col0, void* stream);
+
 /* ---- a14: cp_measure colocalisation -------------------------------------- */
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the

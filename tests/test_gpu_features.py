@@ -163,3 +163,42 @@ def test_zernike_and_mec_match_oracle(engine, objset):
             dphi = np.angle(np.exp(1j * (got[:, 30 + j] - ref[names[30 + j]])))
             ok = (np.abs(dphi) < 1e-4) | (mag < 1e-6 * scale)
             assert ok.all(), (names[30 + j], got[~ok, 30 + j], ref[names[30 + j]][~ok])
+
+
+@pytest.mark.parametrize("objset", ["nuclei", "cells"])
+@pytest.mark.parametrize("mode", ["u16", "f32_unit"])
+def test_texture_matches_oracle(engine, objset, mode):
+    import torch
+    from oracle import texture_restated as tx
+    from aliby_amd.extraction import features as feat
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+
+    f = synth.make_fov(1, 4, shape=(288, 320), n_target=28)
+    labels = f[objset]
+    planes = f["pixels"][:, 0]
+    if mode == "f32_unit":
+        planes = (planes.astype(np.float32) / np.float32(20000.0)).clip(0, 1).astype(np.float32)
+    dl = to_device_u16(labels[None])
+    dp, dt = to_device_planes(planes[None])
+    tab = engine.object_table(dl)
+    names = feat.texture_names(3, 256)
+    for ch in range(planes.shape[0]):
+        out = engine.new_output(tab.n_obj, 52)
+        engine.texture(dl, dp, dt, ch, tab, out, 0)
+        torch.cuda.synchronize()
+        ref = tx.get_texture(labels, planes[ch])
+        _compare(names, out.cpu().numpy(), ref)
+    # a different scale and grey-level count, and an object too small for any pair (NaN row)
+    tiny = np.zeros((64, 64), np.uint16)
+    tiny[10:12, 10:12] = 1
+    tiny[30:50, 20:45] = 2
+    px = np.random.default_rng(2).integers(0, 65535, size=(1, 1, 64, 64), dtype=np.uint16)
+    dl, (dp, dt) = to_device_u16(tiny[None]), to_device_planes(px)
+    tab = engine.object_table(dl)
+    out = engine.new_output(tab.n_obj, 52)
+    engine.texture(dl, dp, dt, 0, tab, out, 0, scale=5, gray_levels=64)
+    torch.cuda.synchronize()
+    ref = tx.get_texture(tiny, px[0, 0], scale=5, gray_levels=64)
+    got = out.cpu().numpy()
+    assert np.isnan(got[0]).all() and np.isnan(ref["Contrast_5_00_64"][0])
+    _compare(feat.texture_names(5, 64), got, ref)
