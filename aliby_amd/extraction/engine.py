@@ -224,6 +224,36 @@ class FeatureEngine:
             )
         return 52
 
+    def radial_geometry(self, labels, table: ObjectTable, bin_count: int) -> torch.Tensor:
+        """Ring/wedge code map [F,Y,X] uint8, computed once per (object table, bin_count)."""
+        cache = getattr(table, "_binmaps", None)
+        if cache is None:
+            cache = table._binmaps = {}
+        if bin_count in cache:
+            return cache[bin_count]
+        F, Y, X = labels.shape
+        binmap = torch.zeros((F, Y, X), dtype=torch.uint8, device=labels.device)
+        with self.timed("radial_geometry"):
+            _lib.check(self.lib.aliby_radial_geometry(self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj,
+                                                      table.max_h, table.max_w, int(bin_count), _ptr(binmap), _stream_ptr()))
+        cache[bin_count] = binmap
+        return binmap
+
+    def radial_distribution(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, bin_count=4,
+                            scaled=True, maximum_radius=100):
+        if not scaled:
+            raise NotImplementedError("radial_distribution(scaled=False) is not built; cp_measure's default is scaled")
+        F, Cn, Y, X = planes.shape
+        binmap = self.radial_geometry(labels, table, bin_count)
+        with self.timed("radial_distribution"):
+            _lib.check(
+                self.lib.aliby_features_radial_distribution(
+                    self.ctx.handle, _ptr(labels), _ptr(binmap), _ptr(planes), dtype, F, Cn, Y, X, int(channel),
+                    _ptr(table.dev), table.n_obj, int(bin_count), _ptr(out), out.stride(0), col0, _stream_ptr(),
+                )
+            )
+        return 3 * bin_count
+
     def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
         """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
         F, Cn, Y, X = planes.shape

@@ -157,6 +157,19 @@ int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, const void* p
                            int n_obj, int max_h, int max_w, int max_area, int scale, int gray_levels,
                            double* out, int ld, int col0, void* stream);
 
+/* cp_measure "radial_distribution" (scaled rings, centre = the object itself), two steps:
+ *  1. aliby_radial_geometry: channel-independent ring/wedge code of every object pixel, written into
+ *     binmap_dev [F,Y,X] (0x80 | wedge<<4 | ring; 0 = not reached from the centre);
+ *  2. aliby_features_radial_distribution: per channel, 3*bin_count columns
+ *     FracAtD_1..n, MeanFrac_1..n, RadialCV_1..n. */
+int aliby_radial_geometry(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                          const aliby_object* table_dev, int n_obj, int max_h, int max_w, int bin_count,
+                          uint8_t* binmap_dev, void* stream);
+int aliby_features_radial_distribution(aliby_ctx* ctx, const uint16_t* labels, const uint8_t* binmap_dev,
+                                       const void* planes, int dtype, int F, int C, int Y, int X,
+                                       int channel, const aliby_object* table_dev, int n_obj,
+                                       int bin_count, double* out, int ld, int col0, void* stream);
+
 /* ---- a14: cp_measure colocalisation -------------------------------------- */
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the

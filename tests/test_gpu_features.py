@@ -202,3 +202,33 @@ def test_texture_matches_oracle(engine, objset, mode):
     got = out.cpu().numpy()
     assert np.isnan(got[0]).all() and np.isnan(ref["Contrast_5_00_64"][0])
     _compare(feat.texture_names(5, 64), got, ref)
+
+
+@pytest.mark.parametrize("objset", ["nuclei", "cells"])
+def test_radial_distribution_matches_oracle(engine, objset):
+    import torch
+    from oracle import radial_restated as rr
+    from aliby_amd.extraction import features as feat
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+
+    f = synth.make_fov(1, 5, shape=(280, 300), n_target=26)
+    labels = f[objset].copy()
+    # one object touching the image border and one concave object (geodesic != straight line)
+    labels[0:14, 40:70] = labels.max() + 1
+    lab_c = labels.max() + 1
+    labels[200:240, 200:206] = lab_c
+    labels[200:206, 200:240] = lab_c
+    labels[234:240, 200:240] = lab_c
+    planes = f["pixels"][:, 0]
+    dl = to_device_u16(labels[None])
+    dp, dt = to_device_planes(planes[None])
+    tab = engine.object_table(dl)
+    for bin_count in (4, 6):
+        names = feat.radial_distribution_names(bin_count)
+        assert names == rr.names(bin_count)
+        for ch in range(planes.shape[0]):
+            out = engine.new_output(tab.n_obj, 3 * bin_count)
+            engine.radial_distribution(dl, dp, dt, ch, tab, out, 0, bin_count=bin_count)
+            torch.cuda.synchronize()
+            ref = rr.get_radial_distribution(labels, planes[ch], bin_count=bin_count)
+            _compare(names, out.cpu().numpy(), ref)
