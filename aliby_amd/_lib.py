@@ -65,6 +65,9 @@ _SIGNATURES = {
     "aliby_label_max": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "aliby_object_table": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "aliby_relabel_sequential": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_masks_workspace_bytes": (_sz, [_i, _i, _i]),
+    "aliby_masks_from_flows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _i, C.c_float, _vp, _sz,
+                                    _vp, _vp, _vp, _vp]),
     "aliby_features_intensity": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_sizeshape": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_feret": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),

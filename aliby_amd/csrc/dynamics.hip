@@ -1,0 +1,696 @@
+// dynamics.hip — Cellpose post-network dynamics: (dY, dX, cellprob) -> label image.
+//
+// Reference call site: `model.eval(...)` at src/aliby/segment/dispatch.py:208-215 (cellpose 4.0.6,
+// uv.lock:130-131 — not vendored, weights not obtainable; PARITY UNPINNED against Cellpose itself).
+// Restated from the published algorithm (cellpose.dynamics.compute_masks):
+//   follow_flows            200 Euler steps p += bilinear(dP/5)(p), torch grid_sample index mapping
+//                           (align_corners=False, zero padding), float32, positions clamped;
+//   get_masks               end-point histogram padded by 20, seeds = 5x5 maxima with > 10 points,
+//                           seed masks grown 5 x (3x3 dilation AND bin > 2) inside an 11x11 window,
+//                           overlaps resolved by (points, raster position) priority, pixel label =
+//                           seed owning its end-point bin, masks > max_size_fraction of the image
+//                           dropped, labels renumbered in order of first raster appearance;
+//   remove_bad_flow_masks   heat diffusion from each mask's centre (2 x max extent iterations, 9-point
+//                           mean restricted to the mask), flows = normalised central differences,
+//                           masks with mean squared error vs dP/5 above flow_threshold dropped;
+//   fill_holes_and_remove_small_masks  masks < min_size dropped, holes filled, labels 1..n.
+// The CPU restatement (oracle/cellpose_restated.py) writes the same float32/float64 operations in the
+// same order, so label images are compared bit-for-bit.
+//
+// Kernel shapes: per-pixel kernels are HBM/L2-bound streaming passes (flow following is an L2-resident
+// gather loop); everything per mask runs as one workgroup per object with its bbox staged in LDS.
+#include "common.h"
+
+typedef unsigned short u16;
+typedef unsigned long long u64;
+
+#define RPAD 20
+
+struct DynShape {
+  int F, Y, X, YP, XP;  // YP = Y + 2*RPAD
+  size_t P, PP;         // pixels per tile, padded cells per tile
+};
+
+// ---------------------------------------------------------------------------------------------
+// 0. normalised, masked flow field: im = ((mask ? dP : 0) / 5) * (2 / (size-1))
+// ---------------------------------------------------------------------------------------------
+__global__ void k_prep_flows(const float* __restrict__ dP, const float* __restrict__ prob, float thr,
+                             DynShape s, float cx, float cy, float* __restrict__ im) {
+  const size_t total = (size_t)s.F * s.P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t f = i / s.P, p = i % s.P;
+    const bool m = prob[i] > thr;
+    float vy = dP[(f * 2 + 0) * s.P + p], vx = dP[(f * 2 + 1) * s.P + p];
+    vy = m ? vy : 0.0f;
+    vx = m ? vx : 0.0f;
+    vy = vy / 5.0f;
+    vx = vx / 5.0f;
+    im[(f * 2 + 0) * s.P + p] = vy * cy;
+    im[(f * 2 + 1) * s.P + p] = vx * cx;
+  }
+}
+
+__device__ __forceinline__ float tap(const float* __restrict__ f, int yy, int xx, int H, int W) {
+  return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? f[(size_t)yy * W + xx] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1. flow following + end-point histogram
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_follow(const float* __restrict__ im, const float* __restrict__ prob,
+                                                float thr, DynShape s, int niter, int* __restrict__ pt,
+                                                int* __restrict__ h1, float* __restrict__ pfinal) {
+  const size_t total = (size_t)s.F * s.P;
+  const int H = s.Y, W = s.X;
+  const float sx = (float)(W - 1), sy = (float)(H - 1), Wf = (float)W, Hf = (float)H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t f = i / s.P, p = i % s.P;
+    if (!(prob[i] > thr)) { pt[i] = -1; continue; }
+    const float* imy = im + (f * 2 + 0) * s.P;
+    const float* imx = im + (f * 2 + 1) * s.P;
+    const int y = (int)(p / W), x = (int)(p % W);
+    float px = (float)x / sx * 2.0f - 1.0f;
+    float py = (float)y / sy * 2.0f - 1.0f;
+    for (int t = 0; t < niter; ++t) {
+      const float ix = ((px + 1.0f) * Wf - 1.0f) / 2.0f;
+      const float iy = ((py + 1.0f) * Hf - 1.0f) / 2.0f;
+      const float x0 = floorf(ix), y0 = floorf(iy);
+      const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+      const float wnw = (x1 - ix) * (y1 - iy);
+      const float wne = (ix - x0) * (y1 - iy);
+      const float wsw = (x1 - ix) * (iy - y0);
+      const float wse = (ix - x0) * (iy - y0);
+      const int x0i = (int)x0, y0i = (int)y0, x1i = (int)x1, y1i = (int)y1;
+      float dx = 0.0f + tap(imx, y0i, x0i, H, W) * wnw;
+      dx = dx + tap(imx, y0i, x1i, H, W) * wne;
+      dx = dx + tap(imx, y1i, x0i, H, W) * wsw;
+      dx = dx + tap(imx, y1i, x1i, H, W) * wse;
+      float dy = 0.0f + tap(imy, y0i, x0i, H, W) * wnw;
+      dy = dy + tap(imy, y0i, x1i, H, W) * wne;
+      dy = dy + tap(imy, y1i, x0i, H, W) * wsw;
+      dy = dy + tap(imy, y1i, x1i, H, W) * wse;
+      px = fminf(fmaxf(px + dx, -1.0f), 1.0f);
+      py = fminf(fmaxf(py + dy, -1.0f), 1.0f);
+    }
+    const float fx = (px + 1.0f) * 0.5f * sx;
+    const float fy = (py + 1.0f) * 0.5f * sy;
+    if (pfinal) { pfinal[(f * 2 + 0) * s.P + p] = fy; pfinal[(f * 2 + 1) * s.P + p] = fx; }
+    float qy = fmaxf(fy + (float)RPAD, 0.0f), qx = fmaxf(fx + (float)RPAD, 0.0f);
+    qy = fminf(qy, (float)(H + RPAD - 1));
+    qx = fminf(qx, (float)(W + RPAD - 1));
+    const int cell = (int)qy * s.XP + (int)qx;
+    pt[i] = cell;
+    atomicAdd(&h1[f * s.PP + cell], 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2. seeds (5x5 maxima with > 10 points) and their grown masks
+// ---------------------------------------------------------------------------------------------
+__global__ void k_seeds(const int* __restrict__ h1, DynShape s, int* __restrict__ seed_list,
+                        int* __restrict__ seed_count, int seed_cap) {
+  const size_t total = (size_t)s.F * s.PP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int h = h1[i];
+    if (h <= 10) continue;
+    const size_t f = i / s.PP;
+    const int cell = (int)(i % s.PP), r = cell / s.XP, c = cell % s.XP;
+    const int* hf = h1 + f * s.PP;
+    bool ismax = true;
+    for (int dr = -2; dr <= 2 && ismax; ++dr)
+      for (int dc = -2; dc <= 2; ++dc) {
+        const int rr = r + dr, cc = c + dc;
+        if (rr < 0 || rr >= s.YP || cc < 0 || cc >= s.XP) continue;
+        if (hf[rr * s.XP + cc] > h) { ismax = false; break; }
+      }
+    if (!ismax) continue;
+    const int k = atomicAdd(seed_count, 1);
+    if (k < seed_cap) { seed_list[2 * k] = (int)f; seed_list[2 * k + 1] = cell; }
+  }
+}
+
+// one wave per seed: 11x11 window, 5 x (3x3 dilation AND h>2); owner = max (points, cell) priority
+__global__ __launch_bounds__(64) void k_grow(const int* __restrict__ h1, DynShape s,
+                                             const int* __restrict__ seed_list, const int* __restrict__ seed_count,
+                                             int seed_cap, u64* __restrict__ M1) {
+  __shared__ unsigned char ok[121], cur[121], nxt[121];
+  const int n = min(*seed_count, seed_cap);
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    const int f = seed_list[2 * k], cell = seed_list[2 * k + 1];
+    const int r0 = cell / s.XP, c0 = cell % s.XP;
+    const int* hf = h1 + (size_t)f * s.PP;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 121; i += 64) {
+      const int rr = r0 - 5 + i / 11, cc = c0 - 5 + i % 11;
+      const bool in = rr >= 0 && rr < s.YP && cc >= 0 && cc < s.XP;
+      ok[i] = (in && hf[rr * s.XP + cc] > 2) ? 1 : 0;
+      cur[i] = (i == 60) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < 5; ++it) {
+      for (int i = threadIdx.x; i < 121; i += 64) {
+        const int r = i / 11, c = i % 11;
+        unsigned char v = 0;
+        for (int dr = -1; dr <= 1; ++dr)
+          for (int dc = -1; dc <= 1; ++dc) {
+            const int rr = r + dr, cc = c + dc;
+            if (rr >= 0 && rr < 11 && cc >= 0 && cc < 11) v |= cur[rr * 11 + cc];
+          }
+        nxt[i] = v & ok[i];
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 121; i += 64) cur[i] = nxt[i];
+      __syncthreads();
+    }
+    const u64 prio = ((u64)(unsigned)hf[cell] << 32) | (u64)(unsigned)cell;
+    for (int i = threadIdx.x; i < 121; i += 64) {
+      if (!cur[i]) continue;
+      const int rr = r0 - 5 + i / 11, cc = c0 - 5 + i % 11;
+      atomicMax(&M1[(size_t)f * s.PP + rr * s.XP + cc], prio + 1ull);  // +1: 0 means "no seed"
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3. pixel labels (temporary id = owning seed's cell + 1), sizes and first raster positions
+// ---------------------------------------------------------------------------------------------
+__global__ void k_assign(const int* __restrict__ pt, const u64* __restrict__ M1, DynShape s,
+                         unsigned int* __restrict__ M0, int* __restrict__ cnt, int* __restrict__ firstpos) {
+  const size_t total = (size_t)s.F * s.P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t f = i / s.P;
+    const int p = (int)(i % s.P);
+    const int cell = pt[i];
+    unsigned int lab = 0;
+    if (cell >= 0) {
+      const u64 m = M1[f * s.PP + cell];
+      if (m) lab = (unsigned int)((m - 1ull) & 0xFFFFFFFFull) + 1u;
+    }
+    M0[i] = lab;
+    if (lab) {
+      atomicAdd(&cnt[f * s.PP + lab - 1], 1);
+      atomicMin(&firstpos[f * s.PP + lab - 1], p);
+    }
+  }
+}
+
+#define SCAN_BLK 1024
+// flag = pixel is the first raster occurrence of a kept label; phase A: per-block counts
+__global__ __launch_bounds__(256) void k_first_counts(const unsigned int* __restrict__ M0, const int* __restrict__ cnt,
+                                                      const int* __restrict__ firstpos, DynShape s, float big,
+                                                      int nblk, int* __restrict__ blockcnt) {
+  __shared__ int red_i[8];
+  const int f = blockIdx.y, b = blockIdx.x;
+  int c = 0;
+  for (int k = threadIdx.x; k < SCAN_BLK; k += blockDim.x) {
+    const size_t p = (size_t)b * SCAN_BLK + k;
+    if (p >= s.P) break;
+    const unsigned int lab = M0[(size_t)f * s.P + p];
+    if (lab && firstpos[(size_t)f * s.PP + lab - 1] == (int)p && !((float)cnt[(size_t)f * s.PP + lab - 1] > big)) ++c;
+  }
+  c = block_sum_i32(c, red_i);
+  if (threadIdx.x == 0) blockcnt[(size_t)f * nblk + b] = c;
+}
+
+// phase B: exclusive scan of block counts (one workgroup per tile); total -> ntot[f]
+__global__ __launch_bounds__(1024) void k_scan_blocks(int* __restrict__ blockcnt, int nblk, int* __restrict__ ntot) {
+  __shared__ int part[1024];
+  const int f = blockIdx.x, t = threadIdx.x;
+  int* bc = blockcnt + (size_t)f * nblk;
+  const int per = (nblk + 1023) / 1024;
+  const int lo = min(t * per, nblk), hi = min(lo + per, nblk);
+  int ssum = 0;
+  for (int i = lo; i < hi; ++i) ssum += bc[i];
+  part[t] = ssum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - ssum;
+  for (int i = lo; i < hi; ++i) { const int c = bc[i]; bc[i] = run; run += c; }
+  if (t == 1023) ntot[f] = part[1023];
+}
+
+// phase C: new id of every kept label = 1 + number of first-occurrence pixels before it
+__global__ __launch_bounds__(256) void k_first_ids(const unsigned int* __restrict__ M0, const int* __restrict__ cnt,
+                                                   const int* __restrict__ firstpos, DynShape s, float big, int nblk,
+                                                   const int* __restrict__ blockbase, int* __restrict__ newid) {
+  __shared__ int wsum[4];
+  const int f = blockIdx.y, b = blockIdx.x;
+  int base = blockbase[(size_t)f * nblk + b];
+  for (int k0 = 0; k0 < SCAN_BLK; k0 += blockDim.x) {
+    const size_t p = (size_t)b * SCAN_BLK + k0 + threadIdx.x;
+    bool flag = false;
+    unsigned int lab = 0;
+    if (p < s.P) {
+      lab = M0[(size_t)f * s.P + p];
+      flag = lab && firstpos[(size_t)f * s.PP + lab - 1] == (int)p && !((float)cnt[(size_t)f * s.PP + lab - 1] > big);
+    }
+    const int pos = block_compact_slot(flag, base, wsum);
+    if (flag) newid[(size_t)f * s.PP + lab - 1] = pos + 1;
+  }
+}
+
+__global__ void k_apply_ids(const unsigned int* __restrict__ M0, const int* __restrict__ newid, DynShape s,
+                            u16* __restrict__ labels) {
+  const size_t total = (size_t)s.F * s.P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t f = i / s.P;
+    const unsigned int lab = M0[i];
+    int id = lab ? newid[f * s.PP + lab - 1] : 0;
+    labels[i] = (u16)(id > 65535 ? 65535 : id);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4. flow QC: heat diffusion per mask, flow error, removal
+// ---------------------------------------------------------------------------------------------
+struct QcArgs {
+  const u16* labels;
+  const float* dP;  // [F,2,Y,X] network-scale flows
+  int F, Y, X;
+  const aliby_object* tab;
+  int n_obj;
+  const int* niter_tile;  // [F]
+  size_t cap_cells;       // >= (max_h+2)*(max_w+2)
+  unsigned char* gscratch;
+  double* Tg;             // [F,Y,X]
+};
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void k_diffuse(QcArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ double red_d[8];
+  __shared__ int red_i[8];
+  __shared__ long long red_l[8];
+  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * a.cap_cells * 17) : lds_raw;
+  double* T0 = reinterpret_cast<double*>(ws);
+  double* T1 = T0 + a.cap_cells;
+  unsigned char* mk = reinterpret_cast<unsigned char*>(T1 + a.cap_cells);
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    if (o.area <= 0) continue;
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, ph = h + 2, pw = w + 2;
+    const u16 L = (u16)o.label;
+    __syncthreads();
+    long long sy = 0, sx = 0;
+    for (int i = tid; i < ph * pw; i += blockDim.x) {
+      const int r = i / pw - 1, c = i % pw - 1;
+      unsigned char m = 0;
+      if (r >= 0 && r < h && c >= 0 && c < w && lab[(size_t)(o.y0 + r) * a.X + o.x0 + c] == L) { m = 1; sy += r; sx += c; }
+      mk[i] = m;
+      T0[i] = 0.0;
+      T1[i] = 0.0;
+    }
+    const long long SY = block_sum_i64(sy, red_l), SX = block_sum_i64(sx, red_l);
+    const double ymed = (double)SY / (double)o.area, xmed = (double)SX / (double)o.area;
+    // mask pixel closest to the centre of mass; first in raster order on ties
+    double best = INFINITY;
+    int bi = INT_MAX;
+    for (int i = tid; i < h * w; i += blockDim.x) {
+      const int r = i / w, c = i % w;
+      if (!mk[(r + 1) * pw + c + 1]) continue;
+      const double dx = (double)c - xmed, dy = (double)r - ymed;
+      const double d = dx * dx + dy * dy;
+      if (d < best) { best = d; bi = i; }
+    }
+    const double BEST = -block_max_f64(-best, red_d);
+    const int CI = block_min_i32(best == BEST ? bi : INT_MAX, red_i);
+    const int cidx = (CI / w + 1) * pw + (CI % w) + 1;
+    const int niter = a.niter_tile[o.tile];
+    double* src = T0;
+    double* dst = T1;
+    for (int it = 0; it < niter; ++it) {
+      __syncthreads();
+      if (tid == 0) src[cidx] += 1.0;
+      __syncthreads();
+      for (int i = tid; i < h * w; i += blockDim.x) {
+        const int q = (i / w + 1) * pw + (i % w) + 1;
+        if (!mk[q]) continue;
+        double acc = 0.0;
+        acc = acc + src[q] * 1.0;
+        acc = acc + src[q - pw] * (double)mk[q - pw];
+        acc = acc + src[q + pw] * (double)mk[q + pw];
+        acc = acc + src[q - 1] * (double)mk[q - 1];
+        acc = acc + src[q + 1] * (double)mk[q + 1];
+        acc = acc + src[q - pw - 1] * (double)mk[q - pw - 1];
+        acc = acc + src[q - pw + 1] * (double)mk[q - pw + 1];
+        acc = acc + src[q + pw - 1] * (double)mk[q + pw - 1];
+        acc = acc + src[q + pw + 1] * (double)mk[q + pw + 1];
+        dst[q] = acc / 9.0;
+      }
+      double* t = src; src = dst; dst = t;
+    }
+    __syncthreads();
+    double* Tt = a.Tg + (size_t)o.tile * plane;
+    for (int i = tid; i < h * w; i += blockDim.x) {
+      const int q = (i / w + 1) * pw + (i % w) + 1;
+      if (mk[q]) Tt[(size_t)(o.y0 + i / w) * a.X + o.x0 + i % w] = src[q];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_flow_error(QcArgs a, float flow_thr, int* __restrict__ bad) {
+  __shared__ double vec[4 * 2];
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    if (o.area <= 0) { if (tid == 0) bad[oi] = 1; continue; }
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const double* T = a.Tg + (size_t)o.tile * plane;
+    const float* dy_net = a.dP + ((size_t)o.tile * 2 + 0) * plane;
+    const float* dx_net = a.dP + ((size_t)o.tile * 2 + 1) * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0;
+    const u16 L = (u16)o.label;
+    double e[2] = {0, 0};
+    for (int i = tid; i < h * w; i += blockDim.x) {
+      const int y = o.y0 + i / w, x = o.x0 + i % w;
+      const size_t idx = (size_t)y * a.X + x;
+      if (lab[idx] != L) continue;
+      const double tu = (y > 0) ? T[idx - a.X] : 0.0, td = (y + 1 < a.Y) ? T[idx + a.X] : 0.0;
+      const double tl = (x > 0) ? T[idx - 1] : 0.0, tr = (x + 1 < a.X) ? T[idx + 1] : 0.0;
+      const double dy = td - tu, dx = tr - tl;
+      const double nrm = 1e-60 + sqrt(dy * dy + dx * dx);
+      const double my = dy / nrm, mx = dx / nrm;
+      const double ey = my - (double)dy_net[idx] / 5.0, ex = mx - (double)dx_net[idx] / 5.0;
+      e[0] += ey * ey;
+      e[1] += ex * ex;
+    }
+    block_sum_vec_all<2>(e, vec);
+    if (tid == 0) {
+      const double err = e[0] / (double)o.area + e[1] / (double)o.area;
+      bad[oi] = (err > (double)flow_thr) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 5. survivors -> final ids; hole filling; small-mask removal
+// ---------------------------------------------------------------------------------------------
+// one workgroup per tile: keep = !bad && area >= min_size; newlabel = rank among kept (1-based)
+__global__ __launch_bounds__(1024) void k_final_ids(const aliby_object* __restrict__ tab, const int* __restrict__ offsets,
+                                                    const int* __restrict__ bad, int min_size,
+                                                    int* __restrict__ newlabel, int* __restrict__ nfinal) {
+  __shared__ int part[1024];
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int lo0 = offsets[f], n = offsets[f + 1] - lo0;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) {
+    const bool keep = !bad[lo0 + i] && tab[lo0 + i].area > 0 && tab[lo0 + i].area >= min_size;
+    c += keep ? 1 : 0;
+  }
+  part[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - c;
+  for (int i = lo; i < hi; ++i) {
+    const bool keep = !bad[lo0 + i] && tab[lo0 + i].area > 0 && tab[lo0 + i].area >= min_size;
+    newlabel[lo0 + i] = keep ? ++run : 0;
+  }
+  if (t == 1023) nfinal[f] = part[1023];
+}
+
+struct FillArgs {
+  const u16* labels;
+  int F, Y, X;
+  const aliby_object* tab;
+  int n_obj;
+  const int* newlabel;
+  size_t cap_cells;
+  unsigned char* gscratch;
+  unsigned int* out32;  // [F,Y,X], zeroed; atomicMax resolves nested holes (highest label wins)
+};
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(256) void k_fill(FillArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ int s_changed;
+  unsigned char* st = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * a.cap_cells) : lds_raw;  // 0 unknown,1 object,2 outside
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const int nl = a.newlabel[oi];
+    if (nl == 0) continue;
+    const aliby_object o = a.tab[oi];
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, ph = h + 2, pw = w + 2;
+    const u16 L = (u16)o.label;
+    __syncthreads();
+    for (int i = tid; i < ph * pw; i += blockDim.x) {
+      const int r = i / pw - 1, c = i % pw - 1;
+      unsigned char v;
+      if (r < 0 || r >= h || c < 0 || c >= w) v = 2;  // ring: outside the bbox is background reachable from outside
+      else v = (lab[(size_t)(o.y0 + r) * a.X + o.x0 + c] == L) ? 1 : 0;
+      st[i] = v;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < ph * pw; ++sweep) {
+      if (tid == 0) s_changed = 0;
+      __syncthreads();
+      int ch = 0;
+      for (int i = tid; i < h * w; i += blockDim.x) {
+        const int q = (i / w + 1) * pw + (i % w) + 1;
+        if (st[q] != 0) continue;
+        if (st[q - 1] == 2 || st[q + 1] == 2 || st[q - pw] == 2 || st[q + pw] == 2) { st[q] = 2; ch = 1; }
+      }
+      if (ch) s_changed = 1;
+      __syncthreads();
+      const int any = s_changed;
+      __syncthreads();
+      if (!any) break;
+    }
+    unsigned int* out = a.out32 + (size_t)o.tile * plane;
+    for (int i = tid; i < h * w; i += blockDim.x) {
+      const int q = (i / w + 1) * pw + (i % w) + 1;
+      if (st[q] != 2) atomicMax(&out[(size_t)(o.y0 + i / w) * a.X + o.x0 + i % w], (unsigned int)nl);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_to_u16(const unsigned int* __restrict__ in, size_t n, u16* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (u16)in[i];
+}
+
+__global__ void k_fill_int(int* p, size_t n, int v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" {
+
+size_t aliby_masks_workspace_bytes(int F, int Y, int X) {
+  const size_t P = (size_t)Y * X, PP = (size_t)(Y + 2 * RPAD) * (X + 2 * RPAD);
+  size_t b = 0;
+  b += align256(sizeof(float) * 2 * P * F);   // im
+  b += align256(sizeof(int) * P * F);         // pt
+  b += align256(sizeof(int) * PP * F) * 3;    // h1/cnt, firstpos, newid
+  b += align256(sizeof(u64) * PP * F);        // M1
+  b += align256(sizeof(unsigned) * P * F);    // M0 / out32
+  b += align256(sizeof(double) * P * F);      // Tg
+  b += align256(sizeof(int) * 2 * 65536 * (size_t)F);  // seed list
+  b += align256(sizeof(int) * ((P + SCAN_BLK - 1) / SCAN_BLK) * F);  // block counts
+  b += align256(sizeof(aliby_object) * 65536 * (size_t)F);  // object table
+  b += align256(sizeof(int) * 65536 * (size_t)F) * 2;  // bad, newlabel
+  b += align256(sizeof(int) * (size_t)(4 * F + 8));    // counters
+  return b;
+}
+
+int aliby_object_table(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X, const int32_t* offsets_host,
+                       aliby_object* table_dev, aliby_object* table_host, void* stream);
+
+int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellprob, int F, int Y, int X, int niter,
+                           float cellprob_threshold, float flow_threshold, int min_size, float max_size_fraction,
+                           void* workspace, size_t workspace_bytes, uint16_t* labels_out, int32_t* n_labels_host,
+                           float* p_final_out, void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  ARG_CHECK(F >= 0 && Y > 1 && X > 1, "bad shape");
+  if (F == 0) return ALIBY_OK;
+  ARG_CHECK(dP && cellprob && workspace && labels_out && n_labels_host, "NULL argument");
+  ARG_CHECK(workspace_bytes >= aliby_masks_workspace_bytes(F, Y, X), "workspace too small (aliby_masks_workspace_bytes)");
+  ARG_CHECK(niter >= 0, "niter must be >= 0");
+  hipStream_t s = as_stream(stream);
+  DynShape sh;
+  sh.F = F; sh.Y = Y; sh.X = X; sh.YP = Y + 2 * RPAD; sh.XP = X + 2 * RPAD;
+  sh.P = (size_t)Y * X; sh.PP = (size_t)sh.YP * sh.XP;
+  const int nblk = (int)((sh.P + SCAN_BLK - 1) / SCAN_BLK);
+  ARG_CHECK(sh.PP < (size_t)INT_MAX && F <= 65535 && nblk <= 65535 * 16, "image too large");
+
+  unsigned char* w = (unsigned char*)workspace;
+  auto take = [&](size_t bytes) { unsigned char* p = w; w += align256(bytes); return p; };
+  float* im = (float*)take(sizeof(float) * 2 * sh.P * F);
+  int* pt = (int*)take(sizeof(int) * sh.P * F);
+  int* h1 = (int*)take(sizeof(int) * sh.PP * F);
+  int* firstpos = (int*)take(sizeof(int) * sh.PP * F);
+  int* newid = (int*)take(sizeof(int) * sh.PP * F);
+  u64* M1 = (u64*)take(sizeof(u64) * sh.PP * F);
+  unsigned* M0 = (unsigned*)take(sizeof(unsigned) * sh.P * F);
+  double* Tg = (double*)take(sizeof(double) * sh.P * F);
+  const int seed_cap = 65536 * F;
+  int* seed_list = (int*)take(sizeof(int) * 2 * 65536 * (size_t)F);
+  int* blockcnt = (int*)take(sizeof(int) * (size_t)nblk * F);
+  aliby_object* tab = (aliby_object*)take(sizeof(aliby_object) * 65536 * (size_t)F);
+  int* bad = (int*)take(sizeof(int) * 65536 * (size_t)F);
+  int* newlabel = (int*)take(sizeof(int) * 65536 * (size_t)F);
+  int* counters = (int*)take(sizeof(int) * (size_t)(4 * F + 8));
+  int* seed_count = counters;
+  int* ntot = counters + 8;          // [F]
+  int* niter_tile = ntot + F;        // [F]
+  int* nfinal = niter_tile + F;      // [F]
+  int* d_offsets = nfinal + F;       // [F+1] (fits: 4F+8 >= 8+3F+F+1 only if ... see below)
+  (void)d_offsets;
+
+  const size_t totP = sh.P * F, totPP = sh.PP * F;
+  const int gP = (int)((totP + 255) / 256 > 16384 ? 16384 : (totP + 255) / 256);
+  const int gPP = (int)((totPP + 255) / 256 > 16384 ? 16384 : (totPP + 255) / 256);
+
+  HIP_TRY(hipMemsetAsync(h1, 0, sizeof(int) * totPP, s));
+  HIP_TRY(hipMemsetAsync(M1, 0, sizeof(u64) * totPP, s));
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(4 * F + 8), s));
+  const float cx = 2.0f / (float)(X - 1), cy = 2.0f / (float)(Y - 1);
+  hipLaunchKernelGGL(k_prep_flows, dim3(gP), dim3(256), 0, s, dP, cellprob, cellprob_threshold, sh, cx, cy, im);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_follow, dim3(gP), dim3(256), 0, s, im, cellprob, cellprob_threshold, sh, niter, pt, h1, p_final_out);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_seeds, dim3(gPP), dim3(256), 0, s, h1, sh, seed_list, seed_count, seed_cap);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_grow, dim3(4096), dim3(64), 0, s, h1, sh, seed_list, seed_count, seed_cap, M1);
+  KERNEL_CHECK();
+  // h1 is free now: reuse as per-label pixel counts
+  int* cnt = h1;
+  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * totPP, s));
+  hipLaunchKernelGGL(k_fill_int, dim3(gPP), dim3(256), 0, s, firstpos, totPP, INT_MAX);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_assign, dim3(gP), dim3(256), 0, s, pt, M1, sh, M0, cnt, firstpos);
+  KERNEL_CHECK();
+  const float big = (float)((double)Y * (double)X * (double)max_size_fraction);
+  hipLaunchKernelGGL(k_first_counts, dim3(nblk, F), dim3(256), 0, s, M0, cnt, firstpos, sh, big, nblk, blockcnt);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_scan_blocks, dim3(F), dim3(1024), 0, s, blockcnt, nblk, ntot);
+  KERNEL_CHECK();
+  HIP_TRY(hipMemsetAsync(newid, 0, sizeof(int) * totPP, s));
+  hipLaunchKernelGGL(k_first_ids, dim3(nblk, F), dim3(256), 0, s, M0, cnt, firstpos, sh, big, nblk, blockcnt, newid);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_apply_ids, dim3(gP), dim3(256), 0, s, M0, newid, sh, labels_out);
+  KERNEL_CHECK();
+  HIP_TRY(hipMemcpyAsync(n_labels_host, ntot, sizeof(int) * F, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int n_obj = 0;
+  for (int f = 0; f < F; ++f) {
+    if (n_labels_host[f] >= 65535) {
+      aliby_set_error("Segmentation produced %d labels; uint16 cast unsafe.", n_labels_host[f]);
+      return ALIBY_ERR_OVERFLOW;
+    }
+    n_obj += n_labels_host[f];
+  }
+  if (n_obj == 0) return ALIBY_OK;  // labels_out is already all zero
+
+  // ---- per-mask stages: object table, flow QC, hole fill ----------------------------------------
+  int* offsets = new int[F + 1];
+  offsets[0] = 0;
+  for (int f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + n_labels_host[f];
+  aliby_object* tab_host = new aliby_object[n_obj];
+  int rc = aliby_object_table(ctx, labels_out, F, Y, X, offsets, tab, tab_host, stream);
+  if (rc) { delete[] offsets; delete[] tab_host; return rc; }
+  int max_h = 0, max_w = 0;
+  int* nit = new int[F];
+  for (int f = 0; f < F; ++f) {
+    int me = 0;
+    for (int i = offsets[f]; i < offsets[f + 1]; ++i) {
+      const int hh = tab_host[i].y1 - tab_host[i].y0, ww = tab_host[i].x1 - tab_host[i].x0;
+      if (tab_host[i].area <= 0) continue;
+      if (hh > max_h) max_h = hh;
+      if (ww > max_w) max_w = ww;
+      if (hh + 1 + ww + 1 > me) me = hh + 1 + ww + 1;
+    }
+    nit[f] = 2 * me;
+  }
+  HIP_TRY(hipMemcpyAsync(niter_tile, nit, sizeof(int) * F, hipMemcpyHostToDevice, s));
+  // offsets for k_final_ids live in ctx scratch (aliby_object_table put them there)
+  const int* d_off = (const int*)ctx->scratch;
+  const size_t cells = ((size_t)(max_h + 2) * (max_w + 2) + 15) & ~(size_t)15;
+
+  if (flow_threshold > 0.0f) {
+    HIP_TRY(hipMemsetAsync(Tg, 0, sizeof(double) * totP, s));
+    QcArgs q;
+    q.labels = labels_out; q.dP = dP; q.F = F; q.Y = Y; q.X = X; q.tab = tab; q.n_obj = n_obj;
+    q.niter_tile = niter_tile; q.cap_cells = cells; q.Tg = Tg;
+    const size_t need = cells * 17;
+    if (need <= 128 * 1024) {
+      q.gscratch = nullptr;
+      if (need > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_diffuse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_diffuse<false>), dim3(n_obj), dim3(256), need, s, q);
+    } else {
+      // ctx scratch holds the offsets in its first bytes: put the slabs after them
+      const int g = n_obj < 256 ? n_obj : 256;
+      const size_t head = align256(sizeof(int) * (size_t)(F + 1));
+      // keep a private copy of the offsets: ensure_scratch may reallocate
+      int rc2 = aliby_ensure_scratch(ctx, head + (size_t)g * need);
+      if (rc2) { delete[] offsets; delete[] tab_host; delete[] nit; return rc2; }
+      HIP_TRY(hipMemcpyAsync(ctx->scratch, offsets, sizeof(int) * (size_t)(F + 1), hipMemcpyHostToDevice, s));
+      d_off = (const int*)ctx->scratch;
+      q.gscratch = (unsigned char*)ctx->scratch + head;
+      hipLaunchKernelGGL((k_diffuse<true>), dim3(g), dim3(256), 0, s, q);
+    }
+    KERNEL_CHECK();
+    hipLaunchKernelGGL(k_flow_error, dim3(n_obj), dim3(256), 0, s, q, flow_threshold, bad);
+    KERNEL_CHECK();
+  } else {
+    HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int) * (size_t)n_obj, s));
+  }
+  hipLaunchKernelGGL(k_final_ids, dim3(F), dim3(1024), 0, s, tab, d_off, bad, min_size, newlabel, nfinal);
+  KERNEL_CHECK();
+  unsigned* out32 = M0;
+  HIP_TRY(hipMemsetAsync(out32, 0, sizeof(unsigned) * totP, s));
+  {
+    FillArgs fa;
+    fa.labels = labels_out; fa.F = F; fa.Y = Y; fa.X = X; fa.tab = tab; fa.n_obj = n_obj; fa.newlabel = newlabel;
+    fa.cap_cells = cells; fa.out32 = out32;
+    if (cells <= 128 * 1024) {
+      fa.gscratch = nullptr;
+      if (cells > 32 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells));
+      hipLaunchKernelGGL((k_fill<false>), dim3(n_obj), dim3(256), cells, s, fa);
+    } else {
+      const int g = n_obj < 256 ? n_obj : 256;
+      const size_t head = align256(sizeof(int) * (size_t)(F + 1));
+      int rc2 = aliby_ensure_scratch(ctx, head + (size_t)g * cells);
+      if (rc2) { delete[] offsets; delete[] tab_host; delete[] nit; return rc2; }
+      fa.gscratch = (unsigned char*)ctx->scratch + head;
+      hipLaunchKernelGGL((k_fill<true>), dim3(g), dim3(256), 0, s, fa);
+    }
+    KERNEL_CHECK();
+  }
+  hipLaunchKernelGGL(k_to_u16, dim3(gP), dim3(256), 0, s, out32, totP, labels_out);
+  KERNEL_CHECK();
+  HIP_TRY(hipMemcpyAsync(n_labels_host, nfinal, sizeof(int) * F, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  delete[] offsets;
+  delete[] tab_host;
+  delete[] nit;
+  return ALIBY_OK;
+}
+
+}  // extern "C"

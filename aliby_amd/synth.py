@@ -111,7 +111,9 @@ def make_pixels(rng, labels, params, n_channels, n_z=1):
 
 
 def analytic_flows(labels):
-    """(dP f32 [2,Y,X] (dy,dx), cellprob f32 [Y,X]) pointing at each object's centre of mass."""
+    """Network-scale outputs for a label image: dP f32 [2,Y,X] (dy,dx) = 5 x unit vectors pointing at each
+    object's centre of mass (Cellpose trains on 5 x the normalised diffusion gradient and divides by 5
+    before following), cellprob f32 [Y,X] = +6 inside / -6 outside."""
     n = int(labels.max())
     Y, X = labels.shape
     dP = np.zeros((2, Y, X), np.float32)
@@ -130,8 +132,8 @@ def analytic_flows(labels):
     nrm[nrm < 1e-6] = 1.0
     # cellpose flows have magnitude <~1 far from the centre and vanish at the centre
     mag = np.clip(np.sqrt(dy * dy + dx * dx) / 3.0, 0.0, 1.0)
-    dP[0] = (dy / nrm * mag).astype(np.float32)
-    dP[1] = (dx / nrm * mag).astype(np.float32)
+    dP[0] = (5.0 * dy / nrm * mag).astype(np.float32)
+    dP[1] = (5.0 * dx / nrm * mag).astype(np.float32)
     prob[inside] = 6.0
     return dP, prob
 

@@ -52,7 +52,9 @@ def build_tree(channels, supported):
         return out
 
     from aliby_amd.extraction import families
+    from aliby_amd.extraction.engine import FeatureEngine
 
+    families.register_optional(FeatureEngine)
     return keep(mono, families.MONO), keep(multi, families.MULTI), sorted(missing)
 
 

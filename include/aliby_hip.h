@@ -116,6 +116,20 @@ int aliby_object_table(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int
 int aliby_relabel_sequential(aliby_ctx* ctx, uint16_t* labels, int F, int Y, int X,
                              int32_t* n_host, void* stream);
 
+/* ---- a6': Cellpose post-network dynamics ---------------------------------- */
+/* What `model.eval` (segment/dispatch.py:208-215; cellpose.dynamics.compute_masks) does after the
+ * network for 2-D images: dP [dev] is [F,2,Y,X] float32 (dY,dX at network scale), cellprob [dev] is
+ * [F,Y,X]; labels_out [dev] receives uint16 labels 1..n per tile, n_labels_host[F] the counts.
+ * Defaults of the reference's call: niter=200, cellprob_threshold=0, flow_threshold=0.4,
+ * min_size=15, max_size_fraction=0.4.  workspace [dev] >= aliby_masks_workspace_bytes(F,Y,X).
+ * p_final_out [dev, optional] receives the flow-following end points [F,2,Y,X] (debug/tests).
+ * Raises ALIBY_ERR_OVERFLOW when a tile would need >= 65535 labels (dispatch.py:230-233). */
+size_t aliby_masks_workspace_bytes(int F, int Y, int X);
+int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellprob, int F, int Y, int X,
+                           int niter, float cellprob_threshold, float flow_threshold, int min_size,
+                           float max_size_fraction, void* workspace, size_t workspace_bytes,
+                           uint16_t* labels_out, int32_t* n_labels_host, float* p_final_out, void* stream);
+
 /* ---- a13: cp_measure single-image features ------------------------------ */
 /* Call site wrap_cp_measure_features (loaders.py:135-150): fun(mask.astype(uint16), pixels).
  * planes [dev] is [F, C, Y, X] (already z-reduced); channel selects the plane.

@@ -425,10 +425,18 @@ def get_feret(masks, pixels=None):
 
 def get_core_measurements():
     """cp_measure.bulk.get_core_measurements() restated: name -> f(masks, pixels, **kw)."""
+    from oracle.radial_restated import get_radial_distribution
+    from oracle.texture_restated import get_texture
+    from oracle.zernike_restated import get_radial_zernikes, get_zernike
+
     return {
+        "radial_distribution": get_radial_distribution,
+        "radial_zernikes": get_radial_zernikes,
         "intensity": get_intensity,
         "sizeshape": get_sizeshape,
+        "zernike": get_zernike,
         "feret": get_feret,
+        "texture": get_texture,
     }
 
 
