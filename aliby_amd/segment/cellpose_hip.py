@@ -1,0 +1,193 @@
+"""
+`CellposeModel` for MI355X: the object `dispatch_segmenter(kind="cellpose")` builds
+(reference: `CellposeModel(gpu=..., device=...)` at src/aliby/segment/dispatch.py:161,171-175 and its
+`.eval(...)` call at 208-215).
+
+Per batch of tiles [F,Y,X]:
+    normalize99 (HIP) -> zero-pad + 224-px overlapped tiles (HIP) -> residual U-Net forward (PyTorch-ROCm,
+    the only torch compute) -> taper-weighted blending + un-pad (HIP) -> dynamics: flow following,
+    seeds, labels, flow-error QC, hole filling / small-mask removal (HIP).
+
+`flows_override(img_u16 [F,Y,X]) -> (dP [F,2,Y,X], cellprob [F,Y,X])` replaces the network's output
+(the network still runs when `run_network_with_override=True`): Cellpose weights cannot be fetched
+offline, so tests and bench.py feed analytic flows derived from the synthetic
+ground truth into the same dynamics.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+from aliby_amd import _lib
+from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr
+from aliby_amd.segment import dynamics
+
+
+def tile_starts(L, bsize=224, tile_overlap=0.1):
+    tile_overlap = min(0.5, max(0.05, tile_overlap))
+    b = min(bsize, L)
+    n = 1 if L <= bsize else int(np.ceil((1.0 + 2 * tile_overlap) * L / bsize))
+    return np.linspace(0, L - b, n).astype(np.int32), int(b)
+
+
+def pad_amounts(Ly, Lx, div=16, extra=1):
+    out = []
+    for L in (Ly, Lx):
+        lpad = int(div * np.ceil(L / div) - L)
+        out += [extra * div // 2 + lpad // 2, extra * div // 2 + lpad - lpad // 2]
+    return out  # ypad1, ypad2, xpad1, xpad2
+
+
+def taper_mask(by, bx, sig=7.5):
+    def one(b):
+        bs = max(224, b)
+        xm = np.arange(bs)
+        xm = np.abs(xm - xm.mean())
+        m = 1 / (1 + np.exp((xm - (bs / 2 - 20)) / sig))
+        return m[bs // 2 - b // 2 : bs // 2 + b // 2 + b % 2]
+
+    return (one(bx) * one(by)[:, np.newaxis]).astype(np.float32)
+
+
+class CellposeModel:
+    def __init__(self, gpu=True, device=None, pretrained_model=None, net=None, net_dtype="float32", seed=0,
+                 flows_override=None, run_network_with_override=False, bsize=224, tile_overlap=0.1, batch_size=64,
+                 **ignored):
+        if not gpu or not torch.cuda.is_available():
+            raise _lib.AlibyHipError("CellposeModel (HIP) needs a GPU: there is no CPU fallback in this build")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.eng = FeatureEngine(self.device.index if self.device.index is not None else torch.cuda.current_device())
+        self.bsize, self.tile_overlap, self.batch_size = int(bsize), float(tile_overlap), int(batch_size)
+        self.net_dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}[net_dtype]
+        self.flows_override = flows_override
+        self.run_network_with_override = run_network_with_override
+        self.pretrained = pretrained_model is not None or net is not None
+        if net is None:
+            from aliby_amd.segment.unet import build_network
+
+            net = build_network(seed=seed, pretrained_model=pretrained_model, device=self.device)
+        self.net = net.to(self.device).eval()
+        if self.net_dtype != torch.float32:
+            self.net = self.net.to(self.net_dtype)
+        self.net = self.net.to(memory_format=torch.channels_last)
+        if not self.pretrained and flows_override is None:
+            warnings.warn("CellposeModel: no pretrained weights available offline; the network is randomly "
+                          "initialised and its masks are not meaningful (SURVEY.md §0.5).")
+        self._geom_cache = {}
+
+    # ------------------------------------------------------------------ reference-side helpers
+    def select_and_project(self, pixels, channel: int) -> torch.Tensor:
+        """pixels [F,C,Z,Y,X] (host uint16 array or device tensor) -> device uint16 [F,Y,X]:
+        channel select + max over Z (dispatch.py:192,199-206)."""
+        if isinstance(pixels, torch.Tensor):
+            dev = pixels.to(self.device)
+        else:
+            pixels = np.ascontiguousarray(pixels)
+            if pixels.dtype != np.uint16:
+                raise NotImplementedError(f"the HIP segmentation path handles uint16 pixels, got {pixels.dtype}")
+            dev = torch.from_numpy(pixels).to(self.device)
+        dev = dev.contiguous()
+        F, C, Z, Y, X = dev.shape
+        out = torch.empty((F, Y, X), dtype=torch.uint16, device=self.device)
+        with self.eng.timed("select_project"):
+            _lib.check(self.eng.lib.aliby_select_project_u16(self.eng.ctx.handle, _ptr(dev), F, C, Z, Y, X, int(channel),
+                                                             _ptr(out), _stream_ptr()))
+        return out
+
+    def max_project_and_relabel(self, labels: torch.Tensor) -> torch.Tensor:
+        """labels [F,Y,X] -> [Y,X]: max over axis 0 then relabel_sequential (dispatch.py:218-223)."""
+        F, Y, X = labels.shape
+        out = torch.empty((1, Y, X), dtype=torch.uint16, device=labels.device)
+        from aliby_amd import _lib as L
+
+        _lib.check(self.eng.lib.aliby_reduce_z(self.eng.ctx.handle, _ptr(labels.contiguous()), L.U16, 1, F, Y * X, L.RED_MAX,
+                                               _ptr(out), L.U16, _stream_ptr()))
+        self.eng.relabel_sequential(out)
+        return out[0]
+
+    def count_labels(self, labels: torch.Tensor) -> int:
+        mx = np.zeros(1, np.int32)
+        lab = labels.reshape(1, -1, labels.shape[-1])
+        _lib.check(self.eng.lib.aliby_label_max(self.eng.ctx.handle, _ptr(lab), 1, lab.shape[1], lab.shape[2], _ptr(mx),
+                                                _stream_ptr()))
+        return int(mx[0])
+
+    # ------------------------------------------------------------------------------ network leg
+    def _geometry(self, Y, X):
+        key = (Y, X)
+        if key not in self._geom_cache:
+            yp1, yp2, xp1, xp2 = pad_amounts(Y, X)
+            Ly, Lx = Y + yp1 + yp2, X + xp1 + xp2
+            ys, by = tile_starts(Ly, self.bsize, self.tile_overlap)
+            xs, bx = tile_starts(Lx, self.bsize, self.tile_overlap)
+            self._geom_cache[key] = dict(
+                ypad1=yp1, xpad1=xp1, Ly=Ly, Lx=Lx, by=by, bx=bx, ny=len(ys), nx=len(xs),
+                ys=torch.from_numpy(ys).to(self.device), xs=torch.from_numpy(xs).to(self.device),
+                taper=torch.from_numpy(taper_mask(by, bx)).to(self.device),
+            )
+        return self._geom_cache[key]
+
+    def normalize(self, img_u16: torch.Tensor) -> torch.Tensor:
+        F, Y, X = img_u16.shape
+        out = torch.empty((F, Y, X), dtype=torch.float32, device=self.device)
+        pct = torch.empty((F, 2), dtype=torch.float64, device=self.device)
+        with self.eng.timed("normalize99"):
+            _lib.check(self.eng.lib.aliby_normalize99_u16(self.eng.ctx.handle, _ptr(img_u16), F, Y, X, 1.0, 99.0, _ptr(out),
+                                                          _ptr(pct), _stream_ptr()))
+        return out
+
+    def run_network(self, img_u16: torch.Tensor):
+        """uint16 [F,Y,X] -> (dP float32 [F,2,Y,X], cellprob float32 [F,Y,X]) through the U-Net."""
+        F, Y, X = img_u16.shape
+        g = self._geometry(Y, X)
+        lib, h = self.eng.lib, self.eng.ctx.handle
+        norm = self.normalize(img_u16)
+        ntiles = F * g["ny"] * g["nx"]
+        tiles = torch.empty((ntiles, 2, g["by"], g["bx"]), dtype=torch.float32, device=self.device)
+        with self.eng.timed("make_tiles"):
+            _lib.check(lib.aliby_make_tiles(h, _ptr(norm), F, Y, X, g["ypad1"], g["xpad1"], g["Ly"], g["Lx"], g["by"],
+                                            g["bx"], g["ny"], g["nx"], _ptr(g["ys"]), _ptr(g["xs"]), 2, _ptr(tiles),
+                                            _stream_ptr()))
+        yt = torch.empty((ntiles, 3, g["by"], g["bx"]), dtype=torch.float32, device=self.device)
+        with self.eng.timed("unet_forward"), torch.no_grad():
+            for i in range(0, ntiles, self.batch_size):
+                xb = tiles[i : i + self.batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
+                yb, _ = self.net(xb)
+                yt[i : i + self.batch_size] = yb.to(torch.float32)
+        dP = torch.empty((F, 2, Y, X), dtype=torch.float32, device=self.device)
+        prob = torch.empty((F, Y, X), dtype=torch.float32, device=self.device)
+        with self.eng.timed("average_tiles"):
+            _lib.check(lib.aliby_average_tiles(h, _ptr(yt), F, Y, X, g["ypad1"], g["xpad1"], g["Ly"], g["Lx"], g["by"],
+                                               g["bx"], g["ny"], g["nx"], _ptr(g["ys"]), _ptr(g["xs"]), _ptr(g["taper"]),
+                                               _ptr(dP), _ptr(prob), _stream_ptr()))
+        return dP, prob
+
+    # ------------------------------------------------------------------------------------- eval
+    def eval(self, x, do_3D=False, stitch_threshold=0.0, normalize=True, z_axis=None, niter=None,
+             flow_threshold=0.4, cellprob_threshold=0.0, min_size=15, max_size_fraction=0.4, **unused):
+        """x: uint16 [F,Y,X] (device tensor or host array) -> (masks, flows, styles) like cellpose.
+        masks is a device uint16 tensor, [Y,X] when F == 1 ("Cellpose squeezes dims"), else [F,Y,X]."""
+        if do_3D:
+            raise NotImplementedError("do_3D is not wired by the reference pipeline (SURVEY §8d, C5 note)")
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint16))
+        x = x.to(self.device).contiguous()
+        if x.ndim == 2:
+            x = x[None]
+        if normalize is not True:
+            raise NotImplementedError("only normalize=True (the reference's call) is built")
+        dP = prob = None
+        if self.flows_override is None or self.run_network_with_override:
+            dP, prob = self.run_network(x)
+        if self.flows_override is not None:
+            dP, prob = self.flows_override(x)
+        labels, counts = dynamics.masks_from_flows(
+            self.eng, dP, prob, niter=200 if niter is None else niter, cellprob_threshold=cellprob_threshold,
+            flow_threshold=flow_threshold, min_size=min_size, max_size_fraction=max_size_fraction,
+        )
+        self.last_counts = counts
+        masks = labels[0] if labels.shape[0] == 1 else labels
+        return masks, [None, dP, prob], None

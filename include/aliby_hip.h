@@ -116,6 +116,28 @@ int aliby_object_table(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int
 int aliby_relabel_sequential(aliby_ctx* ctx, uint16_t* labels, int F, int Y, int X,
                              int32_t* n_host, void* stream);
 
+/* ---- a6: segment closure pre-processing ----------------------------------- */
+/* pixels[:, channel_to_segment] then max over Z (segment/dispatch.py:192,199-206):
+ * pixels [dev] [F,C,Z,Y,X] uint16 -> out [dev] [F,Y,X]. */
+int aliby_select_project_u16(aliby_ctx* ctx, const uint16_t* pixels, int F, int C, int Z, int Y, int X,
+                             int channel, uint16_t* out, void* stream);
+/* cellpose.transforms.normalize99 (normalize=True at dispatch.py:203,212): per image
+ * (x - p_lower) / (p_upper - p_lower) as float32, zeros when the range is < 1e-3; percentiles are exact
+ * order statistics with linear interpolation (numpy.percentile).  percentiles_dev [F,2] receives them. */
+int aliby_normalize99_u16(aliby_ctx* ctx, const uint16_t* img, int F, int Y, int X, double lower,
+                          double upper, float* out, double* percentiles_dev, void* stream);
+/* cellpose.transforms.make_tiles on the zero-padded image: tiles [dev] [F*ny*nx, nchan, by, bx]; channel 0
+ * is the image, the others are zero (grayscale input of the 2-channel U-Net). */
+int aliby_make_tiles(aliby_ctx* ctx, const float* img, int F, int Y, int X, int ypad1, int xpad1, int Ly,
+                     int Lx, int by, int bx, int ny, int nx, const int32_t* ystart_dev,
+                     const int32_t* xstart_dev, int nchan, float* tiles, void* stream);
+/* cellpose.transforms.average_tiles + un-padding: network output tiles [F*ny*nx, 3, by, bx] -> dP [F,2,Y,X],
+ * cellprob [F,Y,X], weighted by taper_dev [by,bx] and accumulated in tile order in float32. */
+int aliby_average_tiles(aliby_ctx* ctx, const float* ytiles, int F, int Y, int X, int ypad1, int xpad1,
+                        int Ly, int Lx, int by, int bx, int ny, int nx, const int32_t* ystart_dev,
+                        const int32_t* xstart_dev, const float* taper_dev, float* dP, float* cellprob,
+                        void* stream);
+
 /* ---- a6': Cellpose post-network dynamics ---------------------------------- */
 /* What `model.eval` (segment/dispatch.py:208-215; cellpose.dynamics.compute_masks) does after the
  * network for 2-D images: dP [dev] is [F,2,Y,X] float32 (dY,dX at network scale), cellprob [dev] is
