@@ -1,0 +1,118 @@
+"""
+End-to-end on the GPU: build_pipeline_steps -> run_pipeline_and_post on a synthetic position, the
+caller pattern of examples/01_cell_painting_tiff.py (two object sets, 5 channels, intensity without
+edges + sizeshape, 10 channel pairs x 4 colocalisation metrics).  Checks the profile table against the
+CPU oracle run in the reference's structure and the on-disk layout (profiles/<name>.parquet,
+steps/<name>/<step>/<tp:04d>.npz).
+"""
+
+from copy import deepcopy
+
+import numpy as np
+import pyarrow.parquet
+import pytest
+
+from aliby_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _position(shape=(192, 224), nt=12):
+    f = synth.make_fov(2, 7, shape=shape, n_channels=5, n_target=nt)
+    return f
+
+
+def test_example01_pipeline_matches_oracle(tmp_path, engine):
+    import torch
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+    from aliby_amd.extraction.extract import format_extraction
+    from oracle import aliby_extract as ox
+    from oracle import cellpose_restated as cr
+
+    f = _position()
+    flows = {k: synth.analytic_flows(f[k]) for k in ("nuclei", "cells")}
+
+    def override_for(name):
+        dP, prob = flows[name]
+        return lambda x: (torch.from_numpy(dP[None]).cuda(), torch.from_numpy(prob[None]).cuda())
+
+    base = build_pipeline_steps(
+        channels_to_segment={"nuclei": 0, "cell": 3},
+        channels_to_extract=[0, 1, 2, 3, 4],
+        features_to_extract=("intensity", "sizeshape"),
+        cp_measure_feature_kwargs={"intensity": {"edge_measurements": False}},
+    )
+    assert list(base["steps"]) == ["tile", "segment_nuclei", "segment_cell", "extract_nuclei", "extract_cell",
+                                   "extractmulti_nuclei", "extractmulti_cell"]
+    pipeline = deepcopy(base)
+    pipeline["steps"]["tile"]["image_kwargs"] = {"source": f["pixels"][None]}  # T=1
+    pipeline["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override_for("nuclei"))
+    pipeline["steps"]["segment_cell"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override_for("cells"))
+    profiles, post = run_pipeline_and_post(pipeline=pipeline, pipeline_name="A01__1", output_path=tmp_path, overwrite=False)
+
+    # --- oracle: same steps in the reference's structure
+    pixels = f["pixels"][None]
+    masks = {"nuclei": cr.finish_labels(cr.compute_masks(*flows["nuclei"])),
+             "cell": cr.finish_labels(cr.compute_masks(*flows["cells"]))}
+    n_rows = int(masks["nuclei"].max()) + int(masks["cell"].max())
+    assert profiles.num_rows == n_rows
+    # the prose shape of examples/01:156-158: 4 metadata + 6*78 + 5*16 + 10*8 = 632 columns
+    assert len(profiles.column_names) == 632
+    assert {"metadata_tile", "metadata_label", "metadata_object", "metadata_tp"} <= set(profiles.column_names)
+    assert "0/max/intensity/Intensity_IntegratedIntensity" in profiles.column_names
+    assert "(0, 3)/None/max/pearson/Correlation_Pearson" in profiles.column_names
+    kw = {"intensity": {"edge_measurements": False}}
+    got = profiles.to_pandas().set_index(["metadata_object", "metadata_label"]).sort_index()
+    for obj in ("nuclei", "cell"):
+        t1 = format_extraction(ox.process_tree_masks(base["steps"][f"extract_{obj}"]["tree"], masks[obj], pixels,
+                                                     ox.extract_tree, cp_measure_kwargs=kw))
+        t2 = format_extraction(ox.process_tree_masks(base["steps"][f"extractmulti_{obj}"]["tree"], masks[obj], pixels,
+                                                     ox.extract_tree_multi, cp_measure_kwargs=kw))
+        want = t1.to_pandas().merge(t2.to_pandas(), on=["tile", "label"]).set_index("label").sort_index()
+        sub = got.loc[obj]
+        assert len(sub) == len(want)
+        for col in want.columns:
+            if col == "tile":
+                continue
+            a, b = sub[col].to_numpy(float), want[col].to_numpy(float)
+            if col.endswith("Orientation"):
+                flip = np.isclose(np.abs(a), 45.0) & np.isclose(np.abs(b), 45.0)
+                a, b = a[~flip], b[~flip]
+            assert np.allclose(a, b, rtol=1e-4, atol=1e-8, equal_nan=True), (obj, col, a[:3], b[:3])
+
+    # --- on-disk layout
+    pq = tmp_path / "profiles" / "A01__1.parquet"
+    assert pq.exists()
+    assert pyarrow.parquet.read_table(pq).num_rows == n_rows
+    for step, key in (("segment_nuclei", "nuclei"), ("segment_cell", "cell")):
+        with np.load(tmp_path / "steps" / "A01__1" / step / "0000.npz") as z:
+            assert list(z.keys()) == ["arr_0"]
+            assert np.array_equal(z["arr_0"], masks[key])
+    # resume-by-skip (pipe_core.py:408,446-448)
+    again, post2 = run_pipeline_and_post(pipeline=deepcopy(pipeline), pipeline_name="A01__1", output_path=tmp_path,
+                                         overwrite=False)
+    assert again is None and post2 is None
+
+
+def test_default_builder_pipeline_runs_all_families(tmp_path, engine):
+    """The builder's default feature list (pipe_builder.py:49-56) on one object set: every family present."""
+    import torch
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    f = _position(shape=(160, 176), nt=9)
+    dP, prob = synth.analytic_flows(f["nuclei"])
+    pipeline = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1])
+    pipeline["steps"]["tile"]["image_kwargs"] = {"source": f["pixels"][None, :2]}
+    pipeline["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(
+        flows_override=lambda x: (torch.from_numpy(dP[None]).cuda(), torch.from_numpy(prob[None]).cuda()))
+    profiles, _ = run_pipeline_and_post(pipeline=pipeline, pipeline_name="B02__1", output_path=tmp_path)
+    cols = profiles.column_names
+    per_channel = 60 + 21 + 2 + 52 + 12 + 30  # radial_zernikes, intensity, feret, texture, radial_distribution, zernike
+    assert len(cols) == 4 + 78 + 2 * per_channel + 1 * 8
+    assert profiles.num_rows == int(f["nuclei"].max())
+    for key in ("0/max/texture/Contrast_3_00_256", "1/max/zernike/Zernike_9_9",
+                "0/max/radial_distribution/RadialDistribution_FracAtD_1of4",
+                "1/max/radial_zernikes/RadialDistribution_ZernikePhase_2_2", "None/None/sizeshape/Area"):
+        assert key in cols, key
