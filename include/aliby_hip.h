@@ -155,8 +155,8 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
 /* ---- a13: cp_measure single-image features ------------------------------ */
 /* Call site wrap_cp_measure_features (loaders.py:135-150): fun(mask.astype(uint16), pixels).
  * planes [dev] is [F, C, Y, X] (already z-reduced); channel selects the plane.
- * Rows of `out` follow the object table; columns start at col0 in the order
- * returned by aliby_feature_names(). */
+ * Rows of `out` follow the object table; columns start at col0 in the order listed in
+ * aliby_amd/extraction/features.py (intensity: 21 columns, 16 without the edge block). */
 int aliby_features_intensity(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
                              int F, int C, int Y, int X, int channel,
                              const aliby_object* table_dev, int n_obj, int max_area,

@@ -1,0 +1,257 @@
+"""
+CPU-only checks (run with -m "not gpu"): host logic that needs no GPU, the C-ABI library loading and
+exporting every symbol include/aliby_hip.h declares, and the world_size-2 gloo path of the gather.
+"""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+# ---------------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    lib_path = ROOT / "aliby_amd" / "libaliby_hip.so"
+    if not lib_path.exists():
+        import __graft_entry__ as g
+
+        g.build()
+    header = (ROOT / "include" / "aliby_hip.h").read_text()
+    declared = set(re.findall(r"\b(aliby_[a-z0-9_]+)\s*\(", header))
+    declared -= {"aliby_object", "aliby_ctx"}
+    from aliby_amd import _lib
+
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    handle = ctypes.CDLL(str(lib_path))
+    for name in declared:
+        assert getattr(handle, name) is not None
+    handle.aliby_abi_version.restype = ctypes.c_int
+    assert handle.aliby_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import FeatureEngine
+
+    with pytest.raises(_lib.AlibyHipError):
+        FeatureEngine()
+    with pytest.raises(_lib.AlibyHipError):
+        _lib.Context(0)
+
+
+def test_product_never_imports_oracle():
+    for path in (ROOT / "aliby_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, path
+
+
+# ---------------------------------------------------------------------------------- builder
+def test_build_pipeline_steps_defaults():
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    p = build_pipeline_steps()
+    assert list(p) == ["steps", "passed_data", "passed_methods", "save", "save_interval"]
+    assert list(p["steps"]) == ["tile", "segment_nuclei", "segment_cell", "extract_nuclei", "extract_cell",
+                                "extractmulti_nuclei", "extractmulti_cell"]
+    assert p["steps"]["tile"] == {"tile_size": None}
+    assert p["steps"]["segment_nuclei"] == {"segmenter_kwargs": {"kind": "cellpose"}, "channel_to_segment": 1}
+    assert p["steps"]["segment_cell"]["channel_to_segment"] == 0
+    tree = p["steps"]["extract_nuclei"]["tree"]
+    feats = ("radial_zernikes", "intensity", "feret", "texture", "radial_distribution", "zernike")
+    assert tree == {"None": {"None": ("sizeshape",)}, 1: {"max": feats}, 0: {"max": feats}}
+    assert p["steps"]["extract_nuclei"]["kwargs"] == {"ncores": None}
+    assert p["steps"]["extractmulti_cell"]["tree"] == {(1, 0): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}}}
+    assert p["passed_data"] == {
+        "extract_nuclei": [("masks", "segment_nuclei"), ("pixels", "tile")],
+        "extractmulti_nuclei": [("masks", "segment_nuclei"), ("pixels", "tile")],
+        "extract_cell": [("masks", "segment_cell"), ("pixels", "tile")],
+        "extractmulti_cell": [("masks", "segment_cell"), ("pixels", "tile")],
+    }
+    assert p["passed_methods"] == {"segment_nuclei": ("tile", "get_fczyx"), "segment_cell": ("tile", "get_fczyx")}
+    assert p["save"] == ["segment_nuclei", "segment_cell"] and p["save_interval"] == 1
+
+
+def test_build_pipeline_steps_options():
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 2, 4], features_to_extract=("intensity",),
+                             extract_ncores=3, steps_to_write=["tile"],
+                             cp_measure_feature_kwargs={"intensity": {"edge_measurements": False}})
+    assert p["save"] == ["tile"]
+    assert p["steps"]["extract_nuclei"]["kwargs"] == {"ncores": 3, "cp_measure_kwargs": {"intensity": {"edge_measurements": False}}}
+    assert list(p["steps"]["extractmulti_nuclei"]["tree"]) == [(0, 2), (0, 4), (2, 4)]
+    p = build_pipeline_steps(nahual_addresses="ipc:///tmp/x.ipc")
+    assert p["steps"]["segment_cell"]["segmenter_kwargs"]["kind"] == "nahual_cellpose"
+
+
+# ---------------------------------------------------------------------------------- extraction host logic
+def test_flatten_kv_match_oracle_and_order():
+    from aliby_amd.extraction.extract import flatten, kv
+    from oracle import aliby_extract as ox
+
+    tree = {"None": {"None": ("sizeshape",)}, 1: {"max": ["intensity", "feret"]}, 0: {"max": ["intensity"], "add": ["texture"]}}
+    assert flatten(tree) == ox.flatten(tree)
+    assert kv(flatten(tree)) == ox.kv(ox.flatten(tree)) == [
+        ("None", "None", "sizeshape"), (1, "max", "intensity"), (1, "max", "feret"), (0, "max", "intensity"), (0, "add", "texture")]
+    multi = {(0, 1): {"None": {"max": ["pearson", "rwc"]}}}
+    assert kv(flatten(multi)) == [((0, 1), "None", "max", "pearson"), ((0, 1), "None", "max", "rwc")]
+
+
+def test_format_extraction_contracts():
+    """The reference's contract tests (tests/test_nahual_embed_minimal.py:35-101)."""
+    from itertools import cycle
+
+    from aliby_amd.extraction.extract import format_extraction
+    from aliby_amd.pipe_core import get_profiles_from_state
+
+    emb = np.arange(12, dtype=np.float32).reshape(3, 4)
+    table = format_extraction(((("__", "__"),), (emb,)))
+    assert isinstance(table, pa.Table) and table.num_rows == 3
+    assert len([c for c in table.column_names if c.startswith("X_")]) == 4
+    with pytest.raises(ValueError, match="zip"):
+        format_extraction((cycle((("__", "__"),)), (np.arange(6, dtype=np.float32).reshape(2, 3),)))
+    state = {"data": {"nahual_embed_cells": [np.arange(8, dtype=np.float32).reshape(2, 4),
+                                             np.arange(8, dtype=np.float32).reshape(2, 4) + 100]}}
+    prof = get_profiles_from_state(state, {"steps": {"nahual_embed_cells": {}}})
+    assert prof.num_rows == 4 and set(prof.column("metadata_object").to_pylist()) == {"cells"}
+    assert set(prof.column("metadata_tp").to_pylist()) == {0, 1}
+
+
+def test_format_extraction_pivot_matches_long_records():
+    from aliby_amd.extraction.extract import format_extraction
+    from oracle import aliby_extract as ox
+
+    inst = ((((0, 1), (0, "max", "intensity")), ((0, 1), ("None", "None", "area")), ((0, 2), (0, "max", "intensity"))))
+    res = [{"b": np.array([2.0]), "a": np.array([1.0])}, 7.5, {"b": np.array([4.0]), "a": np.array([3.0])}]
+    t = format_extraction((inst, res))
+    assert t.column_names == ["tile", "label", "0/max/intensity/a", "0/max/intensity/b", "None/None/area/area"]
+    assert t.to_pydict() == {"tile": [0, 0], "label": [1, 2], "0/max/intensity/a": [1.0, 3.0],
+                             "0/max/intensity/b": [2.0, 4.0], "None/None/area/area": [7.5, None]}
+    rows = ox.format_extraction_records((inst, res))
+    assert len(rows) == 5
+    with pytest.raises(Exception, match="invalid value"):
+        format_extraction(((((0, 1), (0, "max", "x")),), ["nope"]))
+
+
+def test_validate_pipeline_errors():
+    from aliby_amd.pipe_core import validate_pipeline
+
+    good = {"steps": {"tile": {}, "segment_x": {}}, "passed_data": {"segment_x": [("a", "tile")]}}
+    validate_pipeline(good)
+    with pytest.raises(TypeError):
+        validate_pipeline([])
+    with pytest.raises(ValueError, match="'steps'"):
+        validate_pipeline({"passed_data": {}})
+    with pytest.raises(ValueError, match="not defined in 'steps'"):
+        validate_pipeline({"steps": {"tile": {}}, "passed_data": {"x": [("a", "nope")]}})
+    with pytest.raises(ValueError, match="save_interval"):
+        validate_pipeline({**good, "save_interval": 0})
+    with pytest.raises(ValueError, match="listed in 'save'"):
+        validate_pipeline({**good, "save": ["zzz"]})
+    with pytest.raises(ValueError, match="retain"):
+        validate_pipeline({**good, "retain": {"tile": -1}})
+    with pytest.raises(ValueError, match="too small"):
+        validate_pipeline({"steps": {"segment_x": {}, "track": {}}, "passed_data": {"track": [("masks", "segment_x")]},
+                           "retain": {"segment_x": 1}})
+    with pytest.raises(ValueError, match="address"):
+        validate_pipeline({"steps": {"nahual_embed_x": {}}, "passed_data": {}})
+
+
+def test_init_step_dispatch_and_errors():
+    from aliby_amd.pipe import init_step
+
+    with pytest.raises(ValueError, match="Invalid step name"):
+        init_step("bogus", {})
+    with pytest.raises(ValueError, match="image_kwargs"):
+        init_step("tile", {"tile_size": None})
+    with pytest.raises(ValueError, match="channel_to_segment"):
+        init_step("segment_nuclei", {"segmenter_kwargs": {"kind": "cellpose"}})
+    with pytest.raises(ValueError, match="'tree'"):
+        init_step("extract_nuclei", {})
+    f = init_step("extract_nuclei", {"tree": {"None": {"None": ["sizeshape"]}}, "kwargs": {"ncores": None}})
+    assert f.func.__name__ == "process_tree_masks" and f.keywords["measure_fn"].__name__ == "extract_tree"
+    f = init_step("extractmulti_nuclei", {"tree": {}})
+    assert f.keywords["measure_fn"].__name__ == "extract_tree_multi"
+
+
+def test_write_ndarray_layout(tmp_path):
+    from aliby_amd.io.write import dispatch_write_fn, write_ndarray
+    from aliby_amd.pipe_core import _load_per_tp_masks
+
+    lab = np.arange(12, dtype=np.uint16).reshape(1, 3, 4)
+    assert dispatch_write_fn("segment_nuclei") is write_ndarray
+    write_ndarray(lab, steps_dir=tmp_path, subpath="segment_nuclei", tp=3)
+    with np.load(tmp_path / "segment_nuclei" / "0003.npz") as z:
+        assert list(z.keys()) == ["arr_0"] and np.array_equal(z["arr_0"], lab)
+    write_ndarray({"masks": [lab[0], lab[0] + 1], "metadata": {"a": 1}}, steps_dir=tmp_path, subpath="segment_baby", tp=0)
+    with np.load(tmp_path / "segment_baby" / "0000.npz") as z:
+        assert sorted(z.keys()) == ["tile_0", "tile_1"]
+    assert (tmp_path / "segment_baby" / "0000_meta.json").exists()
+    assert np.array_equal(_load_per_tp_masks(tmp_path / "segment_nuclei")[0], lab[0])
+    with pytest.raises(Exception, match="not supported"):
+        dispatch_write_fn("extract_x")
+
+
+def test_feature_name_counts_reproduce_example01_identity():
+    from aliby_amd.extraction import features as feat
+
+    S, I, P = len(feat.sizeshape_names()), len(feat.intensity_names(False)), sum(len(v) for v in feat.COLOC.values())
+    assert (S, I, P) == (78, 16, 8)
+    assert 4 + 6 * S + 5 * I + 10 * P == 632  # examples/01_cell_painting_tiff.py:156-158
+    assert len(feat.zernike_names()) == 30 and len(feat.radial_zernike_names()) == 60
+    assert len(feat.texture_names()) == 52 and len(feat.radial_distribution_names()) == 12
+
+
+# ---------------------------------------------------------------------------------- multi-process (gloo)
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["REPO"])
+from aliby_amd import parallel
+rank, world, _ = parallel.init("gloo")
+mine = parallel.positions_for_rank(7, rank, world)
+vals = torch.tensor([[float(p), p * 10.0] for p in mine], dtype=torch.float64).reshape(-1, 2)
+meta = torch.tensor([[p, rank, 0, 0] for p in mine], dtype=torch.int64).reshape(-1, 4)
+v, m = parallel.gather_rows(vals, meta)
+if rank == 0:
+    assert v.shape == (7, 2) and sorted(m[:, 0].tolist()) == list(range(7))
+    assert m[:, 1].tolist() == [0, 0, 0, 0, 1, 1, 1]
+    assert torch.equal(v[:, 1], v[:, 0] * 10)
+    print("GATHER_OK")
+else:
+    assert v is None and m is None
+parallel.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_gather_rows_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, REPO=str(ROOT), MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29617", str(script)],
+        env=env, capture_output=True, text=True, timeout=240,
+    )
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GATHER_OK" in out.stdout
+
+
+def test_positions_for_rank_partition():
+    from aliby_amd.parallel import positions_for_rank
+
+    for world in (1, 2, 4, 8):
+        got = sorted(p for r in range(world) for p in positions_for_rank(37, r, world))
+        assert got == list(range(37))
