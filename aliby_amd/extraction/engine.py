@@ -254,6 +254,25 @@ class FeatureEngine:
             )
         return 3 * bin_count
 
+    CELL_COLUMNS = ("area", "centroid_x", "centroid_y", "conical_volume", "eccentricity", "spherical_volume", "volume",
+                    "min_ax", "maj_ax", "mean", "median", "std", "total", "total_squared", "max2p5pc", "max5px_median",
+                    "moment_of_inertia")
+
+    def cell_metrics(self, labels, planes, dtype, channel, table: ObjectTable) -> torch.Tensor:
+        """[n_obj, 17] block of the reference's cell.py metrics (planes may be None: mask-only columns)."""
+        F, Y, X = labels.shape
+        Cn = planes.shape[1] if planes is not None else 0
+        out = self.new_output(table.n_obj, 17)
+        with self.timed("cell_metrics"):
+            _lib.check(
+                self.lib.aliby_features_cell(
+                    self.ctx.handle, _ptr(labels), _ptr(planes) if planes is not None else 0, dtype, F, Cn, Y, X,
+                    int(channel) if planes is not None else 0, _ptr(table.dev), table.n_obj, table.max_h, table.max_w,
+                    table.max_area, _ptr(out), out.stride(0) if table.n_obj else 17, 0, _stream_ptr(),
+                )
+            )
+        return out
+
     def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
         """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
         F, Cn, Y, X = planes.shape

@@ -93,6 +93,30 @@ MONO = {
 }
 MULTI = {name: dict(names=(lambda kw, _n=name: list(feat.COLOC[_n]))) for name in feat.COLOC}
 
+# cell.py metrics (loaders.py:19-25): scalar results, one column each; every metric of a (channel, red_z)
+# comes from ONE launch of k_cell whose 17-column block is cached in `cell_cache`.
+_CELL_MASK_ONLY = ("area", "centroid_x", "centroid_y", "conical_volume", "eccentricity", "spherical_volume", "volume")
+_CELL_PIXELS = ("mean", "median", "std", "total", "total_squared", "max2p5pc", "max5px_median", "moment_of_inertia")
+
+
+def _make_cell_launch(metric):
+    def launch(eng, labels, table, plane, dt, ch, out, col0, kw, cell_cache=None):
+        key = (None if plane is None else (plane.data_ptr(), ch))
+        if cell_cache is None:
+            cell_cache = {}
+        if key not in cell_cache:
+            cell_cache[key] = eng.cell_metrics(labels, plane, dt, ch, table)
+        j = eng.CELL_COLUMNS.index(metric)
+        out[:, col0] = cell_cache[key][:, j]
+
+    return launch
+
+
+for _m in _CELL_MASK_ONLY:
+    MONO[_m] = dict(names=lambda kw: None, launch=_make_cell_launch(_m), needs_pixels=False, cell=True)
+for _m in _CELL_PIXELS:
+    MONO[_m] = dict(names=lambda kw: None, launch=_make_cell_launch(_m), needs_pixels=True, cell=True)
+
 
 def register_optional(eng_cls):
     """Families whose kernels are built in later commits register themselves when the engine has them."""
@@ -144,8 +168,10 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
         return out, blocks
 
     done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
+    cell_cache = {}
     for inst, reg, kw, col0, ncols in specs:
         ch, red_z, metric = inst[0], inst[1], inst[-1]
+        extra = {"cell_cache": cell_cache} if reg.get("cell") else {}
         if ch == "None" or not reg["needs_pixels"]:
             if ch != "None" and cache is not None:
                 cache.get(red_z)  # the reference would still reduce (and raise on a bad reducer)
@@ -154,11 +180,11 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
                 # e.g. "feret"/"zernike" listed under every channel: same labels, same numbers
                 out[:, col0 : col0 + ncols] = out[:, done[key] : done[key] + ncols]
             else:
-                reg["launch"](eng, labels, table, None, 0, None, out, col0, kw)
+                reg["launch"](eng, labels, table, None, 0, None, out, col0, kw, **extra)
                 done[key] = col0
         else:
             if cache is None:
                 raise Exception("pixels are required for this instruction")
             plane, dt = cache.get(red_z)
-            reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw)
+            reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw, **extra)
     return out, blocks

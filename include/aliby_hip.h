@@ -206,6 +206,14 @@ int aliby_features_radial_distribution(aliby_ctx* ctx, const uint16_t* labels, c
                                        int channel, const aliby_object* table_dev, int n_obj,
                                        int bin_count, double* out, int ld, int col0, void* stream);
 
+/* ---- a15: the reference's in-repo per-cell metrics ------------------------ */
+/* extraction/core/functions/cell.py:18-303.  17 columns: area, centroid_x, centroid_y, conical_volume,
+ * eccentricity, spherical_volume, volume, min_ax, maj_ax (min_maj_approximation), mean, median, std, total,
+ * total_squared, max2p5pc, max5px_median, moment_of_inertia.  planes may be NULL (mask-only metrics). */
+int aliby_features_cell(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
+                        int Y, int X, int channel, const aliby_object* table_dev, int n_obj, int max_h,
+                        int max_w, int max_area, double* out, int ld, int col0, void* stream);
+
 /* ---- a14: cp_measure colocalisation -------------------------------------- */
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the

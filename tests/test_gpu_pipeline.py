@@ -178,3 +178,29 @@ def test_empty_and_ragged_inputs(engine):
     for a, b in zip(res, res_o):
         for k in b:
             assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-9, equal_nan=True), (k, a[k], b[k])
+
+
+def test_cell_py_metrics_match_reference_restatement(engine):
+    """The reference's in-repo metrics (cell.py) through process_tree_masks; the oracle for them is
+    pinned against the reference module itself (tests/test_oracle_golden.py)."""
+    from aliby_amd.extraction.extract import extract_tree, format_extraction, process_tree_masks
+    from oracle import aliby_extract as ox
+
+    f = synth.make_fov(1, 6, shape=(224, 256), n_target=22)
+    masks = [f["cells"]]
+    pixels = f["pixels"][None]
+    tree = {"None": {"None": ["area", "centroid_x", "centroid_y", "volume", "conical_volume", "spherical_volume", "eccentricity"]},
+            1: {"max": ["mean", "median", "std", "total", "total_squared", "max2p5pc", "max5px_median", "moment_of_inertia"]}}
+    inst, res = process_tree_masks(tree, masks, pixels, extract_tree)
+    inst_o, res_o = ox.process_tree_masks(tree, masks, pixels, ox.extract_tree)
+    assert inst == inst_o and len(res) == len(res_o)
+    for i, (a, b) in enumerate(zip(res, res_o)):
+        assert isinstance(a, float)
+        assert np.isclose(a, float(b), rtol=1e-4, atol=1e-9, equal_nan=True), (inst[i], a, b)
+    t = format_extraction((inst, res))
+    assert "None/None/area/area" in t.column_names and "1/max/max2p5pc/max2p5pc" in t.column_names
+    assert t.num_rows == int(masks[0].max())
+    with pytest.raises(KeyError):
+        process_tree_masks({"None": {"None": ["no_such_metric"]}}, masks, pixels, extract_tree)
+    with pytest.raises(Exception, match="invalid reducer"):
+        process_tree_masks({0: {"mean": ["intensity"]}}, masks, pixels, extract_tree)
