@@ -70,6 +70,11 @@ class CellposeModel:
 
             net = build_network(seed=seed, pretrained_model=pretrained_model, device=self.device)
         self.net = net.to(self.device).eval()
+        self.fused = None
+        if self.net_dtype == torch.bfloat16 and ignored.get("fused", True):
+            from aliby_amd.segment.fused_unet import FusedUNet
+
+            self.fused = FusedUNet(self.net, self.eng)  # keeps fp32 master weights, folds BN, bf16 execution
         if self.net_dtype != torch.float32:
             self.net = self.net.to(self.net_dtype)
         self.net = self.net.to(memory_format=torch.channels_last)
@@ -154,8 +159,11 @@ class CellposeModel:
         yt = torch.empty((ntiles, 3, g["by"], g["bx"]), dtype=torch.float32, device=self.device)
         with self.eng.timed("unet_forward"), torch.no_grad():
             for i in range(0, ntiles, self.batch_size):
-                xb = tiles[i : i + self.batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
-                yb, _ = self.net(xb)
+                if self.fused is not None and g["by"] % 8 == 0 and g["bx"] % 8 == 0:
+                    yb, _ = self.fused(tiles[i : i + self.batch_size])
+                else:
+                    xb = tiles[i : i + self.batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
+                    yb, _ = self.net(xb)
                 yt[i : i + self.batch_size] = yb.to(torch.float32)
         dP = torch.empty((F, 2, Y, X), dtype=torch.float32, device=self.device)
         prob = torch.empty((F, Y, X), dtype=torch.float32, device=self.device)

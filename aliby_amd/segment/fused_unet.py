@@ -1,0 +1,169 @@
+"""
+Fused inference executor for the residual U-Net (aliby_amd/segment/unet.py).
+
+Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
+  * convolutions: torch.nn.functional.conv2d on bf16 channels_last tensors (MIOpen / CK implicit GEMM
+    on the MFMA units) — the only torch compute, as the north star prescribes;
+  * every pointwise stage between two convolutions (BatchNorm affine, ReLU, residual add, style add,
+    nearest 2x upsampling) is ONE pass of the hand-written `k_fused_act` kernel
+    (aliby_amd/csrc/nn_fused.hip) instead of 2-4 eager passes;
+  * BatchNorm in front of the 1x1 projections is folded into their weights; projections of the up path
+    run at the low resolution and are read through the upsample (a 1x1 conv commutes with nearest
+    upsampling).
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from aliby_amd import _lib
+from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+CL = torch.channels_last
+
+
+def _bn_affine(bn):
+    s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    t = bn.bias.float() - bn.running_mean.float() * s
+    return s.contiguous(), t.contiguous()
+
+
+class _Unit:
+    """BN -> ReLU -> Conv with the BN/ReLU done by the fused kernel (scale, shift kept in fp32)."""
+
+    def __init__(self, seq, dtype, pad_in=None):
+        bn, conv = seq[0], seq[-1]
+        self.scale, self.shift = _bn_affine(bn)
+        w = conv.weight.detach().float()
+        if pad_in is not None and w.shape[1] < pad_in:
+            w = F.pad(w, (0, 0, 0, 0, 0, pad_in - w.shape[1]))
+            self.scale = F.pad(self.scale, (0, pad_in - self.scale.shape[0]), value=1.0)
+            self.shift = F.pad(self.shift, (0, pad_in - self.shift.shape[0]))
+        self.w = w.to(dtype).contiguous(memory_format=CL)
+        self.b = conv.bias.detach().to(dtype)
+        self.pad = conv.padding
+
+
+class _Proj:
+    """BN -> 1x1 Conv folded into a single 1x1 conv."""
+
+    def __init__(self, seq, dtype, pad_in=None):
+        bn, conv = seq[0], seq[-1]
+        s, t = _bn_affine(bn)
+        w = conv.weight.detach().float()  # [O, I, 1, 1]
+        b = conv.bias.detach().float() + (w[:, :, 0, 0] @ t)
+        w = w * s[None, :, None, None]
+        if pad_in is not None and w.shape[1] < pad_in:
+            w = F.pad(w, (0, 0, 0, 0, 0, pad_in - w.shape[1]))
+        self.w = w.to(dtype).contiguous(memory_format=CL)
+        self.b = b.to(dtype)
+
+
+class FusedUNet:
+    def __init__(self, net, eng, dtype=torch.bfloat16):
+        assert dtype == torch.bfloat16, "the fused pointwise kernel is bf16"
+        self.eng, self.dtype = eng, dtype
+        self.lib, self.h = eng.lib, eng.ctx.handle
+        net = net.float().eval()
+        self.down = []
+        for i, blk in enumerate(net.down):
+            pad = 8 if i == 0 else None
+            self.down.append(dict(proj=_Proj(blk.proj, dtype, pad), u=[_Unit(blk.conv[0], dtype, pad)] + [_Unit(blk.conv[k], dtype) for k in (1, 2, 3)]))
+        self.up = []
+        for blk in net.up:
+            d = dict(proj=_Proj(blk.proj, dtype), u=[_Unit(blk.conv0, dtype)])
+            for su in (blk.conv1, blk.conv2, blk.conv3):
+                u = _Unit(su.conv, dtype)
+                u.full_w = su.full.weight.detach().float().t().contiguous()  # [style, C]
+                u.full_b = su.full.bias.detach().float()
+                d["u"].append(u)
+            self.up.append(d)
+        self.out = _Unit(net.output, dtype)
+        self.cin = net.nbase[0]
+
+    # -------------------------------------------------------------------------------- kernels
+    def _new(self, n, c, h, w):
+        return torch.empty((n, c, h, w), dtype=self.dtype, device="cuda", memory_format=CL)
+
+    def _fused(self, A, B=None, want_sum=False, act=None, shift=None, upA=False, upB=False, relu=True):
+        """A, B: [N,C,h,w] channels_last bf16.  Returns (SUM or None, ACT or None) at the output resolution."""
+        n, c = A.shape[0], A.shape[1]
+        H = A.shape[2] * (2 if upA else 1)
+        W = A.shape[3] * (2 if upA else 1)
+        S = self._new(n, c, H, W) if want_sum else None
+        T = self._new(n, c, H, W) if act is not None else None
+        per_sample = 0
+        sh = None
+        if act is not None:
+            sh = shift if shift is not None else act.shift
+            per_sample = 1 if sh.ndim == 2 else 0
+        _lib.check(self.lib.aliby_nn_fused_act_bf16(
+            self.h, _ptr(A), _ptr(B) if B is not None else 0, _ptr(S) if S is not None else 0, _ptr(T) if T is not None else 0,
+            _ptr(act.scale) if act is not None else 0, _ptr(sh) if sh is not None else 0, n, H, W, c, 1 if upA else 0,
+            1 if upB else 0, 1 if relu else 0, per_sample, _stream_ptr()))
+        return S, T
+
+    @staticmethod
+    def _conv(x, unit, pad=1):
+        return F.conv2d(x, unit.w, unit.b, padding=pad)
+
+    # -------------------------------------------------------------------------------- forward
+    @torch.no_grad()
+    def __call__(self, tiles: torch.Tensor):
+        """tiles float32 [N, cin, H, W] (contiguous NCHW) -> (y float32 [N,3,H,W], style float32 [N,256])."""
+        n, cin, H, W = tiles.shape
+        d0 = self.down[0]
+        raw = self._new(n, 8, H, W)
+        act = self._new(n, 8, H, W)
+        _lib.check(self.lib.aliby_nn_tiles_to_nhwc8_bf16(self.h, _ptr(tiles), n, cin, H, W, _ptr(d0["u"][0].scale),
+                                                         _ptr(d0["u"][0].shift), _ptr(raw), _ptr(act), _stream_ptr()))
+        feats = []
+        x_raw, x_act = raw, act
+        for i, d in enumerate(self.down):
+            u = d["u"]
+            if i > 0:
+                x_raw = F.max_pool2d(feats[-1], 2, 2)
+                _, x_act = self._fused(x_raw, act=u[0])
+            p = self._conv(x_raw, d["proj"], pad=0)
+            c0 = self._conv(x_act, u[0])
+            _, a1 = self._fused(c0, act=u[1])
+            c1 = self._conv(a1, u[1])
+            x1, a2 = self._fused(p, c1, want_sum=True, act=u[2])
+            c2 = self._conv(a2, u[2])
+            _, a3 = self._fused(c2, act=u[3])
+            c3 = self._conv(a3, u[3])
+            x2, _ = self._fused(x1, c3, want_sum=True)
+            feats.append(x2)
+        style = feats[-1].float().mean(dim=(2, 3))
+        style = style / torch.sum(style**2, dim=1, keepdim=True) ** 0.5
+        x, up = feats[-1], False
+        for i in range(len(self.up) - 1, -1, -1):
+            d = self.up[i]
+            u = d["u"]
+            skip = feats[i]
+            p_low = self._conv(x, d["proj"], pad=0)                 # at x's resolution; read through the upsample below
+            _, a0 = self._fused(x, act=u[0], upA=up)
+            c0 = self._conv(a0, u[0])
+            sh = [(style @ k.full_w + k.full_b) * k.scale + k.shift for k in u[1:]]  # [N,C] each
+            _, a1 = self._fused(c0, skip, act=u[1], shift=sh[0].contiguous())
+            c1 = self._conv(a1, u[1])
+            x1, a2 = self._fused_up_sum(p_low, c1, up, u[2], sh[1].contiguous())
+            c2 = self._conv(a2, u[2])
+            _, a3 = self._fused(c2, act=u[3], shift=sh[2].contiguous())
+            c3 = self._conv(a3, u[3])
+            x, _ = self._fused(x1, c3, want_sum=True)
+            up = True
+        _, a = self._fused(x, act=self.out)
+        y = self._conv(a, self.out, pad=0)
+        return y.float().contiguous(), style
+
+    def _fused_up_sum(self, p_low, c1, up, unit, shift):
+        """x1 = upsample?(p_low) + c1 ; a2 = relu(bn(x1) + style shift).  A must be the full-resolution operand
+        for the output shape, so the (possibly low-res) projection goes in slot B."""
+        n, c, H, W = c1.shape
+        S, T = self._new(n, c, H, W), self._new(n, c, H, W)
+        _lib.check(self.lib.aliby_nn_fused_act_bf16(
+            self.h, _ptr(c1), _ptr(p_low), _ptr(S), _ptr(T), _ptr(unit.scale), _ptr(shift), n, H, W, c, 0, 1 if up else 0, 1, 1,
+            _stream_ptr()))
+        return S, T

@@ -179,3 +179,29 @@ def test_segment_step_matches_reference_closure_semantics(engine):
     assert np.array_equal(labels, want)
     with pytest.raises(Exception, match="Invalid segmentation method"):
         dispatch_segmenter(kind="nope", channel_to_segment=0)
+
+
+def test_fused_unet_matches_module_forward(engine):
+    """FusedUNet (HIP pointwise kernel + MIOpen convs, bf16) vs the plain fp32 module forward."""
+    import torch
+    from aliby_amd.segment.fused_unet import FusedUNet
+    from aliby_amd.segment.unet import build_network
+
+    net = build_network(seed=5, device="cuda")
+    # make BatchNorm statistics and affine parameters non-trivial so that every folded term is exercised
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    x = torch.randn(6, 2, 224, 224, generator=g).cuda().contiguous()
+    with torch.no_grad():
+        y_ref, s_ref = net(x)
+    fused = FusedUNet(net, engine)
+    y, s = fused(x)
+    assert y.shape == y_ref.shape == (6, 3, 224, 224) and y.dtype == torch.float32
+    err = (y - y_ref).norm() / y_ref.norm()
+    assert err < 0.03, float(err)
+    assert ((s - s_ref).norm() / s_ref.norm()) < 0.03
