@@ -41,7 +41,7 @@ class _Unit:
             self.scale = F.pad(self.scale, (0, pad_in - self.scale.shape[0]), value=1.0)
             self.shift = F.pad(self.shift, (0, pad_in - self.shift.shape[0]))
         self.w = w.to(dtype).contiguous(memory_format=CL)
-        self.b = conv.bias.detach().to(dtype)
+        self.bias = conv.bias.detach().float().contiguous()  # folded into the next fused pointwise pass
         self.pad = conv.padding
 
 
@@ -57,7 +57,7 @@ class _Proj:
         if pad_in is not None and w.shape[1] < pad_in:
             w = F.pad(w, (0, 0, 0, 0, 0, pad_in - w.shape[1]))
         self.w = w.to(dtype).contiguous(memory_format=CL)
-        self.b = b.to(dtype)
+        self.bias = b.contiguous()
 
 
 class FusedUNet:
@@ -69,7 +69,9 @@ class FusedUNet:
         self.down = []
         for i, blk in enumerate(net.down):
             pad = 8 if i == 0 else None
-            self.down.append(dict(proj=_Proj(blk.proj, dtype, pad), u=[_Unit(blk.conv[0], dtype, pad)] + [_Unit(blk.conv[k], dtype) for k in (1, 2, 3)]))
+            d = dict(proj=_Proj(blk.proj, dtype, pad), u=[_Unit(blk.conv[0], dtype, pad)] + [_Unit(blk.conv[k], dtype) for k in (1, 2, 3)])
+            d["pb1"] = (d["proj"].bias + d["u"][1].bias).contiguous()
+            self.down.append(d)
         self.up = []
         for blk in net.up:
             d = dict(proj=_Proj(blk.proj, dtype), u=[_Unit(blk.conv0, dtype)])
@@ -78,6 +80,7 @@ class FusedUNet:
                 u.full_w = su.full.weight.detach().float().t().contiguous()  # [style, C]
                 u.full_b = su.full.bias.detach().float()
                 d["u"].append(u)
+            d["pb1"] = (d["proj"].bias + d["u"][1].bias).contiguous()
             self.up.append(d)
         self.out = _Unit(net.output, dtype)
         self.cin = net.nbase[0]
@@ -86,7 +89,7 @@ class FusedUNet:
     def _new(self, n, c, h, w):
         return torch.empty((n, c, h, w), dtype=self.dtype, device="cuda", memory_format=CL)
 
-    def _fused(self, A, B=None, want_sum=False, act=None, shift=None, upA=False, upB=False, relu=True):
+    def _fused(self, A, B=None, want_sum=False, act=None, shift=None, upA=False, upB=False, relu=True, bias=None):
         """A, B: [N,C,h,w] channels_last bf16.  Returns (SUM or None, ACT or None) at the output resolution."""
         n, c = A.shape[0], A.shape[1]
         H = A.shape[2] * (2 if upA else 1)
@@ -100,13 +103,14 @@ class FusedUNet:
             per_sample = 1 if sh.ndim == 2 else 0
         _lib.check(self.lib.aliby_nn_fused_act_bf16(
             self.h, _ptr(A), _ptr(B) if B is not None else 0, _ptr(S) if S is not None else 0, _ptr(T) if T is not None else 0,
+            _ptr(bias) if bias is not None else 0,
             _ptr(act.scale) if act is not None else 0, _ptr(sh) if sh is not None else 0, n, H, W, c, 1 if upA else 0,
             1 if upB else 0, 1 if relu else 0, per_sample, _stream_ptr()))
         return S, T
 
     @staticmethod
     def _conv(x, unit, pad=1):
-        return F.conv2d(x, unit.w, unit.b, padding=pad)
+        return F.conv2d(x, unit.w, None, padding=pad)  # bias is applied by the next fused pass
 
     # -------------------------------------------------------------------------------- forward
     @torch.no_grad()
@@ -127,13 +131,13 @@ class FusedUNet:
                 _, x_act = self._fused(x_raw, act=u[0])
             p = self._conv(x_raw, d["proj"], pad=0)
             c0 = self._conv(x_act, u[0])
-            _, a1 = self._fused(c0, act=u[1])
+            _, a1 = self._fused(c0, act=u[1], bias=u[0].bias)
             c1 = self._conv(a1, u[1])
-            x1, a2 = self._fused(p, c1, want_sum=True, act=u[2])
+            x1, a2 = self._fused(p, c1, want_sum=True, act=u[2], bias=d["pb1"])
             c2 = self._conv(a2, u[2])
-            _, a3 = self._fused(c2, act=u[3])
+            _, a3 = self._fused(c2, act=u[3], bias=u[2].bias)
             c3 = self._conv(a3, u[3])
-            x2, _ = self._fused(x1, c3, want_sum=True)
+            x2, _ = self._fused(x1, c3, want_sum=True, bias=u[3].bias)
             feats.append(x2)
         style = feats[-1].float().mean(dim=(2, 3))
         style = style / torch.sum(style**2, dim=1, keepdim=True) ** 0.5
@@ -146,24 +150,28 @@ class FusedUNet:
             _, a0 = self._fused(x, act=u[0], upA=up)
             c0 = self._conv(a0, u[0])
             sh = [(style @ k.full_w + k.full_b) * k.scale + k.shift for k in u[1:]]  # [N,C] each
-            _, a1 = self._fused(c0, skip, act=u[1], shift=sh[0].contiguous())
+            _, a1 = self._fused(c0, skip, act=u[1], shift=sh[0].contiguous(), bias=u[0].bias)
             c1 = self._conv(a1, u[1])
-            x1, a2 = self._fused_up_sum(p_low, c1, up, u[2], sh[1].contiguous())
+            x1, a2 = self._fused_up_sum(p_low, c1, up, u[2], sh[1].contiguous(), d["pb1"])
             c2 = self._conv(a2, u[2])
-            _, a3 = self._fused(c2, act=u[3], shift=sh[2].contiguous())
+            _, a3 = self._fused(c2, act=u[3], shift=sh[2].contiguous(), bias=u[2].bias)
             c3 = self._conv(a3, u[3])
-            x, _ = self._fused(x1, c3, want_sum=True)
+            x, _ = self._fused(x1, c3, want_sum=True, bias=u[3].bias)
             up = True
         _, a = self._fused(x, act=self.out)
-        y = self._conv(a, self.out, pad=0)
-        return y.float().contiguous(), style
+        yb = self._conv(a, self.out, pad=0)  # [N,3,H,W] channels_last == NHWC with 3 channels
+        y = torch.empty((n, yb.shape[1], H, W), dtype=torch.float32, device="cuda")
+        _lib.check(self.lib.aliby_nn_nhwc_to_nchw_f32(self.h, _ptr(yb), n, H, W, yb.shape[1], yb.shape[1], _ptr(self.out.bias),
+                                                      _ptr(y), _stream_ptr()))
+        return y, style
 
-    def _fused_up_sum(self, p_low, c1, up, unit, shift):
+    def _fused_up_sum(self, p_low, c1, up, unit, shift, bias):
         """x1 = upsample?(p_low) + c1 ; a2 = relu(bn(x1) + style shift).  A must be the full-resolution operand
         for the output shape, so the (possibly low-res) projection goes in slot B."""
         n, c, H, W = c1.shape
         S, T = self._new(n, c, H, W), self._new(n, c, H, W)
         _lib.check(self.lib.aliby_nn_fused_act_bf16(
-            self.h, _ptr(c1), _ptr(p_low), _ptr(S), _ptr(T), _ptr(unit.scale), _ptr(shift), n, H, W, c, 0, 1 if up else 0, 1, 1,
+            self.h, _ptr(c1), _ptr(p_low), _ptr(S), _ptr(T), _ptr(bias), _ptr(unit.scale), _ptr(shift), n, H, W, c, 0,
+            1 if up else 0, 1, 1,
             _stream_ptr()))
         return S, T

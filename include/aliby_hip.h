@@ -138,13 +138,17 @@ int aliby_average_tiles(aliby_ctx* ctx, const float* ytiles, int F, int Y, int X
                         const int32_t* xstart_dev, const float* taper_dev, float* dP, float* cellprob,
                         void* stream);
 
-/* Fused pointwise stage between two convolutions of the U-Net (bf16, NHWC): sum = A (+ B), each optionally
- * read through a 2x nearest upsample; act = relu?(scale[c]*sum + shift[n,c] or shift[c]).  SUM and/or ACT
- * are written.  Replaces eager BatchNorm / ReLU / add / style-add / upsample passes of the network that
- * `model.eval` (segment/dispatch.py:208-215) runs; the convolutions themselves stay in PyTorch-ROCm. */
+/* Fused pointwise stage between two convolutions of the U-Net (bf16, NHWC): sum = A (+ B) (+ bias[c]), A/B
+ * optionally read through a 2x nearest upsample; act = relu?(scale[c]*sum + shift[n,c] or shift[c]).  SUM
+ * and/or ACT are written.  Replaces the eager conv-bias / BatchNorm / ReLU / add / style-add / upsample
+ * passes of the network that `model.eval` (segment/dispatch.py:208-215) runs; the convolutions themselves
+ * stay in PyTorch-ROCm. */
 int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* SUM, void* ACT,
-                            const float* scale, const float* shift, int N, int H, int W, int C, int upA,
-                            int upB, int relu, int shift_per_sample, void* stream);
+                            const float* bias, const float* scale, const float* shift, int N, int H, int W,
+                            int C, int upA, int upB, int relu, int shift_per_sample, void* stream);
+/* network output bf16 NHWC [N,H,W,Cpad] (+ bias[Cout]) -> float32 NCHW [N,Cout,H,W]. */
+int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W, int Cpad, int Cout,
+                              const float* bias, float* out, void* stream);
 /* float32 NCHW network tiles (Cin <= 8) -> bf16 NHWC padded to 8 channels: raw copy and relu(bn(x)). */
 int aliby_nn_tiles_to_nhwc8_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W,
                                  const float* scale, const float* shift, void* raw, void* act, void* stream);
