@@ -53,6 +53,10 @@ int aliby_ensure_scratch(aliby_ctx* ctx, size_t bytes);
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// Workgroup size for one-workgroup-per-object kernels: a ~450-pixel nucleus keeps a single wave busy; four
+// waves would spend their time in barriers.  `work` = pixels the workgroup loops over (bbox or area).
+static inline int aliby_pick_block(long long work) { return work <= 2048 ? 64 : (work <= 8192 ? 128 : 256); }
+
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------

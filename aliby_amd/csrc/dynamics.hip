@@ -641,7 +641,7 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
       q.gscratch = nullptr;
       if (need > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_diffuse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      hipLaunchKernelGGL((k_diffuse<false>), dim3(n_obj), dim3(256), need, s, q);
+      hipLaunchKernelGGL((k_diffuse<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), need, s, q);
     } else {
       // ctx scratch holds the offsets in its first bytes: put the slabs after them
       const int g = n_obj < 256 ? n_obj : 256;
@@ -655,7 +655,7 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
       hipLaunchKernelGGL((k_diffuse<true>), dim3(g), dim3(256), 0, s, q);
     }
     KERNEL_CHECK();
-    hipLaunchKernelGGL(k_flow_error, dim3(n_obj), dim3(256), 0, s, q, flow_threshold, bad);
+    hipLaunchKernelGGL(k_flow_error, dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), 0, s, q, flow_threshold, bad);
     KERNEL_CHECK();
   } else {
     HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int) * (size_t)n_obj, s));
@@ -672,7 +672,7 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
       fa.gscratch = nullptr;
       if (cells > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells));
-      hipLaunchKernelGGL((k_fill<false>), dim3(n_obj), dim3(256), cells, s, fa);
+      hipLaunchKernelGGL((k_fill<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), cells, s, fa);
     } else {
       const int g = n_obj < 256 ? n_obj : 256;
       const size_t head = align256(sizeof(int) * (size_t)(F + 1));

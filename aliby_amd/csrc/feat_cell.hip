@@ -248,10 +248,10 @@ extern "C" int aliby_features_cell(aliby_ctx* ctx, const uint16_t* labels, const
     a.gscratch = nullptr;
     if (f32) {
       if (need > 32 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_cell<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      hipLaunchKernelGGL((k_cell<float, false>), dim3(n_obj), dim3(256), need, s, a);
+      hipLaunchKernelGGL((k_cell<float, false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), need, s, a);
     } else {
       if (need > 32 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_cell<u16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      hipLaunchKernelGGL((k_cell<u16, false>), dim3(n_obj), dim3(256), need, s, a);
+      hipLaunchKernelGGL((k_cell<u16, false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), need, s, a);
     }
   } else {
     const int gsz = n_obj < 512 ? n_obj : 512;

@@ -287,7 +287,7 @@ extern "C" int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, cons
   const size_t need = (size_t)cap * 20;
   if (need <= 96 * 1024) {
     a.gscratch = nullptr;
-    dim3 grid(n_obj), block(256);
+    dim3 grid(n_obj), block(aliby_pick_block(max_area));
     if (dtype == ALIBY_U16) {
       if (need > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_coloc<u16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));

@@ -271,7 +271,7 @@ extern "C" int aliby_features_intensity(aliby_ctx* ctx, const uint16_t* labels, 
   const size_t lds_cap = 128 * 1024;
   if (lds_need <= lds_cap) {
     a.gscratch = nullptr;
-    dim3 grid(n_obj), block(256);
+    dim3 grid(n_obj), block(aliby_pick_block(max_area));
     if (dtype == ALIBY_U16) {
       if (lds_need > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_intensity<u16, false>,

@@ -255,7 +255,7 @@ int aliby_radial_geometry(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, 
     a.gscratch = nullptr;
     if (need > 32 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)k_radial_geometry<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-    hipLaunchKernelGGL((k_radial_geometry<false>), dim3(n_obj), dim3(256), need, s, a);
+    hipLaunchKernelGGL((k_radial_geometry<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), need, s, a);
   } else {
     const int g = n_obj < 512 ? n_obj : 512;
     int rc = aliby_ensure_scratch(ctx, (size_t)g * need);

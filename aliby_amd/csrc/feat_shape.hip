@@ -440,13 +440,15 @@ __global__ __launch_bounds__(256) void k_shape_hull(HullArgs a) {
     }
     __syncthreads();
     if ((tid & 63) == 0) {
-      const int wv = tid >> 6;
-      int n;
-      if (wv == 0) n = chain_build(rmin, rmax, 2 * h + 1, true, chains + 0 * chain_cap);
-      else if (wv == 1) n = chain_build(rmin, rmax, 2 * h + 1, false, chains + 1 * chain_cap);
-      else if (wv == 2) n = chain_build(cmin, cmax, h, true, chains + 2 * chain_cap);
-      else n = chain_build(cmin, cmax, h, false, chains + 3 * chain_cap);
-      s_n[wv] = n;
+      // four chains spread over however many waves the workgroup has
+      for (int wv = tid >> 6; wv < 4; wv += (int)(blockDim.x >> 6)) {
+        int n;
+        if (wv == 0) n = chain_build(rmin, rmax, 2 * h + 1, true, chains + 0 * chain_cap);
+        else if (wv == 1) n = chain_build(rmin, rmax, 2 * h + 1, false, chains + 1 * chain_cap);
+        else if (wv == 2) n = chain_build(cmin, cmax, h, true, chains + 2 * chain_cap);
+        else n = chain_build(cmin, cmax, h, false, chains + 3 * chain_cap);
+        s_n[wv] = n;
+      }
     }
     __syncthreads();
     // ---- convex area: bbox pixel centres (doubled: row 2r+1, col 2c) inside or on the diamond hull
@@ -519,7 +521,7 @@ static int launch_hull(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int
     if (a.cap_bytes > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)k_shape_hull<false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.cap_bytes));
-    hipLaunchKernelGGL((k_shape_hull<false>), dim3(n_obj), dim3(256), a.cap_bytes, s, a);
+    hipLaunchKernelGGL((k_shape_hull<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_h)), a.cap_bytes, s, a);
   } else {
     const int g = n_obj < 512 ? n_obj : 512;
     int rc = aliby_ensure_scratch(ctx, (size_t)g * a.cap_bytes);
@@ -571,7 +573,7 @@ extern "C" int aliby_features_sizeshape(aliby_ctx* ctx, const uint16_t* labels, 
       if (need > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_shape_core<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.cap));
-      hipLaunchKernelGGL((k_shape_core<false>), dim3(n_obj), dim3(256), a.cap, s, a);
+      hipLaunchKernelGGL((k_shape_core<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), a.cap, s, a);
     } else {
       const int g = n_obj < 512 ? n_obj : 512;
       int rc = aliby_ensure_scratch(ctx, (size_t)g * a.cap);
@@ -594,7 +596,7 @@ extern "C" int aliby_features_sizeshape(aliby_ctx* ctx, const uint16_t* labels, 
       if (a.cap_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_shape_edt<false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.cap_bytes));
-      hipLaunchKernelGGL((k_shape_edt<false>), dim3(n_obj), dim3(256), a.cap_bytes, s, a);
+      hipLaunchKernelGGL((k_shape_edt<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), a.cap_bytes, s, a);
     } else {
       const int g = n_obj < 512 ? n_obj : 512;
       int rc = aliby_ensure_scratch(ctx, (size_t)g * a.cap_bytes);

@@ -250,7 +250,7 @@ extern "C" int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, co
   hipStream_t s = as_stream(stream);
   if (need <= 96 * 1024) {
     a.gscratch = nullptr;
-    dim3 grid(n_obj), block(256);
+    dim3 grid(n_obj), block(aliby_pick_block((long long)max_h * max_w));
     if (dtype == ALIBY_U16) {
       if (need > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_texture<u16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));

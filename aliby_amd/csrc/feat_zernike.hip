@@ -100,9 +100,9 @@ __global__ __launch_bounds__(256) void k_mec(MecArgs a) {
       if (lab[(size_t)(o.y0 + r) * a.X + o.x0 + c] == L) { atomicMin(&cmin[r], c); atomicMax(&cmax[r], c); }
     }
     __syncthreads();
-    if ((tid & 63) == 0 && (tid >> 6) < 2) {
-      const int wv = tid >> 6;
-      s_n[wv] = chain_build(cmin, cmax, h, wv == 0, wv == 0 ? low : up);
+    if ((tid & 63) == 0) {
+      for (int wv = tid >> 6; wv < 2; wv += (int)(blockDim.x >> 6))
+        s_n[wv] = chain_build(cmin, cmax, h, wv == 0, wv == 0 ? low : up);
     }
     __syncthreads();
     const int nl = s_n[0], nu = s_n[1];
@@ -195,70 +195,133 @@ struct ZernikeArgs {
   int ld, col0;
 };
 
-template <typename T, bool WEIGHTED>
-__global__ __launch_bounds__(256) void k_zernike(ZernikeArgs a) {
-  __shared__ double vec[4 * 2 * ZK];
-  const int tid = threadIdx.x;
-  const size_t plane = (size_t)a.Y * a.X;
-  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
-    const aliby_object o = a.tab[oi];
-    double* out = a.out + (size_t)oi * a.ld + a.col0;
-    const int ncol = WEIGHTED ? 2 * ZK : ZK;
-    if (o.area <= 0) {
-      for (int k = tid; k < ncol; k += blockDim.x) out[k] = NAN;
-      continue;
-    }
-    const u16* lab = a.labels + (size_t)o.tile * plane;
-    const T* px = WEIGHTED ? reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.channel) * plane : nullptr;
-    const double ci = a.mec[(size_t)oi * 4 + 0], cj = a.mec[(size_t)oi * 4 + 1], rad = a.mec[(size_t)oi * 4 + 2];
-    const int h = o.y1 - o.y0, w = o.x1 - o.x0;
-    const u16 L = (u16)o.label;
-    double acc[2 * ZK];
+// local (pass-relative) slot -> global (n,m) column; passes split at m <= 2 | m >= 3 so that a lane never
+// carries more than 32 fp64 accumulators (the single-pass version spilled to scratch)
+__host__ __device__ constexpr int zpass_count(int mlo, int mhi) {
+  int c = 0;
+  for (int m = mlo; m <= mhi; ++m) for (int n = m; n < 10; n += 2) ++c;
+  return c;
+}
+struct ZMap { int g[2][32]; };
+constexpr ZMap make_zmap() {
+  ZMap z{};
+  const int lo[2] = {0, 3}, hi[2] = {2, 9};
+  for (int p = 0; p < 2; ++p) {
+    for (int j = 0; j < 32; ++j) z.g[p][j] = -1;
+    int j = 0;
+    for (int m = lo[p]; m <= hi[p]; ++m)
+      for (int n = m; n < 10; n += 2) { z.g[p][j++] = 2 * zidx(n, m); z.g[p][j++] = 2 * zidx(n, m) + 1; }
+  }
+  return z;
+}
+__device__ __constant__ const ZMap d_zmap = make_zmap();
+
+#define ZROW 17  // padded row of the per-wave transpose buffer (doubles)
+
+// One pass (MLO <= m <= MHI) of one wave over one object's bbox, then an LDS-transposed reduction:
+// 16 values per chunk: every lane writes its 16 partials, lane l sums 16 rows of column l&15, two xor-shuffles
+// combine the 4 row groups.  ~64 LDS ops + 8 shuffles per lane instead of 60 six-step shuffle trees.
+template <typename T, bool WEIGHTED, int PASS, int MLO, int MHI>
+__device__ __forceinline__ void zern_pass(const ZernikeArgs& a, const aliby_object& o, bool valid, int lane, double ci,
+                                          double cj, double rad, const u16* lab, const T* px, double* wred, double* res) {
+  constexpr int KP = zpass_count(MLO, MHI);
+  double acc[2 * KP];
 #pragma unroll
-    for (int k = 0; k < 2 * ZK; ++k) acc[k] = 0;
-    for (int i = tid; i < h * w; i += blockDim.x) {
-      const int yy = o.y0 + i / w, xx = o.x0 + i % w;
+  for (int k = 0; k < 2 * KP; ++k) acc[k] = 0;
+  if (valid) {
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, npix = h * w;
+    const u16 L = (u16)o.label;
+    int r = lane / w, c = lane - r * w;
+    for (int i = lane; i < npix; i += 64) {
+      const int yy = o.y0 + r, xx = o.x0 + c;
       const size_t idx = (size_t)yy * a.X + xx;
+      c += 64;
+      while (c >= w) { c -= w; ++r; }
       if (lab[idx] != L) continue;
       const double y = ((double)yy - ci) / rad, x = ((double)xx - cj) / rad;
       const double r2 = x * x + y * y;
-      double wgt = 1.0;
-      if (WEIGHTED) wgt = (double)px_load<T>(px, idx);
       // zero outside the unit disc.  The 2-3 pixels that DEFINE the enclosing circle sit at r2 = 1 +- 1ulp;
       // a 1e-9 guard band makes their membership independent of rounding (same rule in the oracle).
       if (r2 > 1.0 + 1e-9) continue;
-      // m outer (running power of z = y + i x), n inner: every index below is a compile-time constant
+      double wgt = 1.0;
+      if (WEIGHTED) wgt = (double)px_load<T>(px, idx);
       double zr = 1.0, zi = 0.0;
 #pragma unroll
-      for (int m = 0; m < 10; ++m) {
-        if (m > 0) { const double nr = zr * y - zi * x; zi = zr * x + zi * y; zr = nr; }
+      for (int m = 1; m <= MLO; ++m) { const double nr = zr * y - zi * x; zi = zr * x + zi * y; zr = nr; }
+      int j = 0;
+#pragma unroll
+      for (int m = MLO; m <= MHI; ++m) {
+        if (m > MLO) { const double nr = zr * y - zi * x; zi = zr * x + zi * y; zr = nr; }
 #pragma unroll
         for (int n = m; n < 10; n += 2) {
-          const int k = zidx(n, m);
           double s = 0;
 #pragma unroll
           for (int t = 0; t < ZW; ++t) if (t <= (n - m) / 2) s = s * r2 + zlut(n, m, t);
           s *= wgt;
-          if (m == 0) { acc[2 * k] += s; }
-          else { acc[2 * k] += s * zr; acc[2 * k + 1] += s * zi; }
+          acc[2 * j] += s * zr;
+          acc[2 * j + 1] += s * zi;
+          ++j;
         }
       }
     }
-    block_sum_vec_all<2 * ZK>(acc, vec);
-    __syncthreads();
-    if (tid == 0) {
+  }
+  constexpr int NCH = (2 * KP + 15) / 16;
 #pragma unroll
-      for (int k = 0; k < 2 * ZK; ++k) vec[k] = acc[k];  // static indices only: acc stays in registers
-    }
+  for (int ch = 0; ch < NCH; ++ch) {
     __syncthreads();
-    if (tid < ZK) {
-      const double re = vec[2 * tid], im = vec[2 * tid + 1];
-      const double mag = sqrt(re * re + im * im);
-      if (WEIGHTED) {
-        out[tid] = mag / (double)o.area;
-        out[ZK + tid] = atan2(re, im);
-      } else {
-        out[tid] = mag / (M_PI * rad * rad);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) wred[lane * ZROW + t] = (ch * 16 + t < 2 * KP) ? acc[(ch * 16 + t < 2 * KP) ? ch * 16 + t : 0] : 0.0;
+    __syncthreads();
+    const int col = lane & 15, part = lane >> 4;
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += wred[(part * 16 + q) * ZROW + col];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const int slot = ch * 16 + col;
+    if (part == 0 && slot < 2 * KP) res[d_zmap.g[PASS][slot]] = s;
+  }
+}
+
+// one WAVE per object (4 objects per 256-thread workgroup)
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_zernike(ZernikeArgs a) {
+  __shared__ double s_wred[4][64 * ZROW];
+  __shared__ double s_res[4][2 * ZK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t plane = (size_t)a.Y * a.X;
+  const int ncol = WEIGHTED ? 2 * ZK : ZK;
+  for (int base = blockIdx.x * 4; base < a.n_obj; base += gridDim.x * 4) {
+    const int oi = base + wv;
+    const bool inrange = oi < a.n_obj;
+    aliby_object o;
+    o.area = 0;
+    if (inrange) o = a.tab[oi];
+    const bool valid = inrange && o.area > 0;
+    double ci = 0, cj = 0, rad = 1;
+    const u16* lab = nullptr;
+    const T* px = nullptr;
+    if (valid) {
+      ci = a.mec[(size_t)oi * 4 + 0]; cj = a.mec[(size_t)oi * 4 + 1]; rad = a.mec[(size_t)oi * 4 + 2];
+      lab = a.labels + (size_t)o.tile * plane;
+      if (WEIGHTED) px = reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.channel) * plane;
+    }
+    zern_pass<T, WEIGHTED, 0, 0, 2>(a, o, valid, lane, ci, cj, rad, lab, px, s_wred[wv], s_res[wv]);
+    zern_pass<T, WEIGHTED, 1, 3, 9>(a, o, valid, lane, ci, cj, rad, lab, px, s_wred[wv], s_res[wv]);
+    __syncthreads();
+    if (inrange) {
+      double* out = a.out + (size_t)oi * a.ld + a.col0;
+      if (!valid) {
+        for (int k = lane; k < ncol; k += 64) out[k] = NAN;
+      } else if (lane < ZK) {
+        const double re = s_res[wv][2 * lane], im = s_res[wv][2 * lane + 1];
+        const double mag = sqrt(re * re + im * im);
+        if (WEIGHTED) {
+          out[lane] = mag / (double)o.area;
+          out[ZK + lane] = atan2(re, im);
+        } else {
+          out[lane] = mag / (M_PI * rad * rad);
+        }
       }
     }
     __syncthreads();
@@ -282,7 +345,7 @@ int aliby_object_mec(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X
     a.gscratch = nullptr;
     if (a.cap_bytes > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)k_mec<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.cap_bytes));
-    hipLaunchKernelGGL((k_mec<false>), dim3(n_obj), dim3(256), a.cap_bytes, s, a);
+    hipLaunchKernelGGL((k_mec<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_h)), a.cap_bytes, s, a);
   } else {
     const int g = n_obj < 512 ? n_obj : 512;
     int rc = aliby_ensure_scratch(ctx, (size_t)g * a.cap_bytes);
@@ -312,7 +375,7 @@ int aliby_features_zernike(aliby_ctx* ctx, const uint16_t* labels, const void* p
   a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.channel = channel;
   a.tab = table_dev; a.n_obj = n_obj; a.mec = mec_dev; a.out = out; a.ld = ld; a.col0 = col0;
   hipStream_t s = as_stream(stream);
-  dim3 grid(n_obj), block(256);
+  dim3 grid((n_obj + 3) / 4), block(256);
   if (!weighted) hipLaunchKernelGGL((k_zernike<u16, false>), grid, block, 0, s, a);
   else if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_zernike<u16, true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((k_zernike<float, true>), grid, block, 0, s, a);
