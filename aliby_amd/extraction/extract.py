@@ -171,7 +171,7 @@ def _run(tileid_instructions, masks, pixels, cp_measure_kwargs, multi):
     matrix_dev, blocks = families.evaluate(
         eng, labels, table, planes, instructions, cp_measure_kwargs or {}, multi=multi
     )
-    matrix = matrix_dev.cpu().numpy()
+    matrix = eng.to_host(matrix_dev)
     # rows of the matrix follow the table: every label 1..max of every tile
     row_of = {}
     offs = table.offsets

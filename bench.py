@@ -152,7 +152,7 @@ def main():
         m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
         m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
         with eng.timed("rows_d2h"):
-            rows = (m1.cpu(), m2.cpu())
+            rows = (torch.from_numpy(eng.to_host(m1, copy=False)), torch.from_numpy(eng.to_host(m2, copy=False)))
         return rows, table, model.last_counts
 
     def barrier():
