@@ -84,6 +84,7 @@ class FusedUNet:
             self.up.append(d)
         self.out = _Unit(net.output, dtype)
         self.cin = net.nbase[0]
+        self.bytes_moved = 0  # bytes read+written by the fused pointwise launches while profiling is on
 
     # -------------------------------------------------------------------------------- kernels
     def _new(self, n, c, h, w):
@@ -101,7 +102,10 @@ class FusedUNet:
         if act is not None:
             sh = shift if shift is not None else act.shift
             per_sample = 1 if sh.ndim == 2 else 0
-        _lib.check(self.lib.aliby_nn_fused_act_bf16(
+        if self.eng.profile is not None:
+            self.bytes_moved += 2 * (A.numel() + (B.numel() if B is not None else 0) + (n * c * H * W) * ((S is not None) + (T is not None)))
+        with self.eng.timed("fused_pointwise"):
+          _lib.check(self.lib.aliby_nn_fused_act_bf16(
             self.h, _ptr(A), _ptr(B) if B is not None else 0, _ptr(S) if S is not None else 0, _ptr(T) if T is not None else 0,
             _ptr(bias) if bias is not None else 0,
             _ptr(act.scale) if act is not None else 0, _ptr(sh) if sh is not None else 0, n, H, W, c, 1 if upA else 0,
@@ -170,7 +174,10 @@ class FusedUNet:
         for the output shape, so the (possibly low-res) projection goes in slot B."""
         n, c, H, W = c1.shape
         S, T = self._new(n, c, H, W), self._new(n, c, H, W)
-        _lib.check(self.lib.aliby_nn_fused_act_bf16(
+        if self.eng.profile is not None:
+            self.bytes_moved += 2 * (c1.numel() + p_low.numel() + 2 * c1.numel())
+        with self.eng.timed("fused_pointwise"):
+          _lib.check(self.lib.aliby_nn_fused_act_bf16(
             self.h, _ptr(c1), _ptr(p_low), _ptr(S), _ptr(T), _ptr(bias), _ptr(unit.scale), _ptr(shift), n, H, W, c, 0,
             1 if up else 0, 1, 1,
             _stream_ptr()))
