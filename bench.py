@@ -201,8 +201,14 @@ def main():
     if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the launches
         ab = model.fused.bytes_moved / launches
     achieved = ab / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    # FETCH_SIZE doubled on gfx950): measured offline, committed under profiles/, see profiles/pmc_traffic.json
+    traffic = None
+    pmc_file = ROOT / "profiles" / "pmc_traffic.json"
+    if pmc_file.exists():
+        traffic = json.loads(pmc_file.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
     roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": ab,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches}
     net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(args.steps, 1)
     hip_in_net_ms = prof.get("fused_pointwise", {}).get("ms_total", 0.0) / max(args.steps, 1)
