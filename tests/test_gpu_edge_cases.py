@@ -1,0 +1,98 @@
+"""
+GPU parity on the edge cases: objects too large for LDS (global-scratch kernel variants), float32 pixel
+planes, several tiles with ragged label counts, Z > 1 reduced once on the device, maximum label values.
+"""
+
+import numpy as np
+import pytest
+
+from aliby_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, key, rtol=1e-4):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    if key.endswith("Orientation"):
+        flip = np.isclose(np.abs(a), 45.0) & np.isclose(np.abs(b), 45.0)
+        a, b = a[~flip], b[~flip]
+    assert np.allclose(a, b, rtol=rtol, atol=1e-8, equal_nan=True), (key, a[:4], b[:4])
+
+
+def _run_both(tree, masks, pixels, multi=False, kw=None):
+    from aliby_amd.extraction.extract import extract_tree, extract_tree_multi, process_tree_masks
+    from oracle import aliby_extract as ox
+
+    fn, fo = (extract_tree_multi, ox.extract_tree_multi) if multi else (extract_tree, ox.extract_tree)
+    inst, res = process_tree_masks(tree, masks, pixels, fn, cp_measure_kwargs=kw)
+    inst_o, res_o = ox.process_tree_masks(tree, masks, pixels, fo, cp_measure_kwargs=kw)
+    assert inst == inst_o and len(res) == len(res_o)
+    for i, (a, b) in enumerate(zip(res, res_o)):
+        if isinstance(b, dict):
+            assert set(a) == set(b)
+            for k in b:
+                _close(a[k], b[k], f"{inst[i][1]}/{k}")
+        else:
+            _close(a, float(b), str(inst[i][1]))
+    return inst, res
+
+
+def test_huge_objects_use_global_scratch_and_match(engine):
+    """One object of ~46k pixels (does not fit any LDS budget) next to small ones, every family."""
+    Y, X = 320, 352
+    lab = np.zeros((Y, X), np.uint16)
+    yy, xx = np.mgrid[0:Y, 0:X]
+    lab[((yy - 150) / 120.0) ** 2 + ((xx - 170) / 130.0) ** 2 <= 1.0] = 1          # big ellipse
+    lab[((yy - 150) / 20.0) ** 2 + ((xx - 170) / 25.0) ** 2 <= 1.0] = 0            # with a hole
+    lab[290:300, 300:330] = 2
+    lab[5:9, 5:9] = 3
+    rng = np.random.default_rng(4)
+    px = rng.integers(200, 40000, size=(1, 2, 1, Y, X)).astype(np.uint16)
+    for c in range(2):
+        px[0, c, 0][lab == 1] += (2000 * np.sin(xx[lab == 1] / (9.0 + c)) + 2000).astype(np.uint16)
+    feats = ["intensity", "feret", "zernike", "radial_zernikes", "texture", "radial_distribution"]
+    tree = {"None": {"None": ["sizeshape", "area", "volume"]}, 0: {"max": feats + ["median", "max2p5pc"]}}
+    _run_both(tree, [lab], px)
+    _run_both({(0, 1): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}}}, [lab], px, multi=True)
+
+
+def test_float32_planes_every_family(engine):
+    f = synth.make_fov(1, 8, shape=(192, 208), n_channels=2, n_target=14)
+    pixels = (f["pixels"].astype(np.float32) / np.float32(30000.0)).clip(0, 1)[None]  # [1,C,1,Y,X] float32 in [0,1]
+    tree = {0: {"max": ["intensity", "radial_zernikes", "texture", "radial_distribution", "mean", "std", "median"]}}
+    _run_both(tree, [f["cells"]], pixels)
+    _run_both({(0, 1): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}}}, [f["cells"]], pixels, multi=True)
+
+
+def test_ragged_tiles_and_z_reduction(engine):
+    """Three tiles with 0 / few / many objects and Z = 3: one max-projection on the device."""
+    tiles = [synth.make_fov(4, k, shape=(160, 176), n_channels=2, n_z=3, n_target=n) for k, n in ((0, 10), (1, 4))]
+    masks = [tiles[0]["nuclei"], np.zeros((160, 176), np.uint16), tiles[1]["cells"]]
+    pixels = np.stack([tiles[0]["pixels"], tiles[0]["pixels"][::-1].copy(), tiles[1]["pixels"]])  # [3,2,3,Y,X]
+    tree = {"None": {"None": ["sizeshape"]}, 1: {"max": ["intensity", "texture"]}, 0: {"max": ["intensity"]}}
+    inst, res = _run_both(tree, masks, pixels)
+    tiles_seen = sorted({t[0][0] for t in inst})
+    assert tiles_seen == [0, 2]
+    _run_both({(0, 1): {"None": {"max": ["pearson", "rwc"]}}}, masks, pixels, multi=True)
+    # per-feature kwargs reach the kernels
+    _run_both({0: {"max": ["intensity", "texture", "radial_distribution"]}}, masks, pixels,
+              kw={"intensity": {"edge_measurements": False}, "texture": {"scale": 2}, "radial_distribution": {"bin_count": 5}})
+
+
+def test_label_values_up_to_uint16_limit(engine):
+    """Sparse label ids near 65534: rows exist for 1..max (absent ones NaN), as process_tree_masks enumerates."""
+    from aliby_amd.extraction.extract import extract_tree, process_tree_masks
+
+    lab = np.zeros((64, 64), np.uint16)
+    lab[4:10, 4:10] = 1
+    lab[20:30, 20:40] = 300
+    px = np.random.default_rng(0).integers(0, 9000, size=(1, 1, 1, 64, 64), dtype=np.uint16)
+    inst, res = process_tree_masks({0: {"max": ["intensity"]}}, [lab], px, extract_tree)
+    assert len(res) == 300
+    assert res[0]["Intensity_MaxIntensity"][0] == px[0, 0, 0][lab == 1].max()
+    assert np.isnan(res[150]["Intensity_MeanIntensity"][0])
+    assert np.isclose(res[299]["Intensity_MeanIntensity"][0], px[0, 0, 0][lab == 300].mean())
+    from aliby_amd.segment.dispatch import _to_uint16_labels
+
+    with pytest.raises(OverflowError):
+        _to_uint16_labels(np.array([[65535]], dtype=np.int64))
