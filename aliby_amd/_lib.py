@@ -85,7 +85,8 @@ _SIGNATURES = {
     "aliby_features_radial_distribution": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_cell": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_coloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i,
-                                  C.c_double, C.c_double, _vp]),
+                                  C.c_double, C.c_double, _vp, _vp, _vp]),
+    "aliby_object_ranks": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -118,6 +118,10 @@ __device__ __forceinline__ int wave_min(int v) {
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;      \
     const int nw = (blockDim.x + WAVE - 1) / WAVE;                            \
     v = WOP(v);                                                               \
+    if (nw == 1) { /* single-wave workgroup: no LDS round trip */             \
+      __syncthreads();                                                        \
+      return __shfl(v, 0, WAVE);                                              \
+    }                                                                         \
     __syncthreads();                                                          \
     if (lane == 0) red[wid] = v;                                              \
     __syncthreads();                                                          \
@@ -160,6 +164,11 @@ template <int K>
 __device__ __forceinline__ void block_sum_vec_all(double (&v)[K], double* lds) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
+  if (nw == 1) {  // single-wave workgroup: shuffles only
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = __shfl(wave_sum(v[k]), 0, WAVE);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     double s = wave_sum(v[k]);
@@ -198,11 +207,18 @@ __device__ __forceinline__ void block_inclusive_scan(int* a, int n, int* part) {
   const int lo = min(t * per, n), hi = min(lo + per, n);
   int s = 0;
   for (int i = lo; i < hi; ++i) { s += a[i]; a[i] = s; }
+  // exclusive prefix of the per-thread totals: shuffle scan inside the wave, LDS only across waves
+  const int lane = t & 63, wid = t >> 6, nw = (nt + 63) >> 6;
+  int incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  int off = incl - s;
   __syncthreads();
-  part[t] = s;
-  __syncthreads();
-  int off = 0;
-  for (int i = 0; i < t; ++i) off += part[i];
+  if (nw > 1) {
+    if (lane == 63) part[wid] = incl;
+    __syncthreads();
+    for (int i = 0; i < wid; ++i) off += part[i];
+  }
   if (off) for (int i = lo; i < hi; ++i) a[i] += off;
   __syncthreads();
 }

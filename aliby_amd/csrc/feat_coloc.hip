@@ -34,6 +34,8 @@ struct ColocArgs {
   int col_pearson, col_manders, col_rwc, col_costes;  // -1 = not requested
   double thr;        // percent of the maximum (15)
   double scale_max;  // costes candidate scale (255)
+  const unsigned int* ranks;  // [F,C,Y,X] dense per-object ranks (aliby_object_ranks), needed for rwc
+  const int* rmax;            // [n_obj, C] largest rank per (object, channel)
 };
 
 template <typename T, bool GLOBAL>
@@ -44,14 +46,11 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
   __shared__ float red_f[8];
   __shared__ int red_i[8];
   __shared__ int wsum[4];
-  __shared__ int part[256];
-
-  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * (size_t)a.cap * 20) : lds_raw;
+  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * (size_t)a.cap * 16) : lds_raw;
   float* fv = reinterpret_cast<float*>(ws);
   float* sv = fv + a.cap;
-  float* S = sv + a.cap;
-  int* P = reinterpret_cast<int*>(S + a.cap);
-  int* r1 = P + a.cap;
+  unsigned int* rk1 = reinterpret_cast<unsigned int*>(sv + a.cap);
+  unsigned int* rk2 = rk1 + a.cap;
   const int tid = threadIdx.x;
   const size_t plane = (size_t)a.Y * a.X;
 
@@ -85,7 +84,13 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
         in = lab[idx] == L;
       }
       const int pos = block_compact_slot(in, base, wsum);
-      if (in) { fv[pos] = px_load<T>(p0, idx); sv[pos] = px_load<T>(p1, idx); }
+      if (in) {
+        fv[pos] = px_load<T>(p0, idx); sv[pos] = px_load<T>(p1, idx);
+        if (a.col_rwc >= 0) {
+          rk1[pos] = a.ranks[((size_t)o.tile * a.C + a.ch0) * plane + idx];
+          rk2[pos] = a.ranks[((size_t)o.tile * a.C + a.ch1) * plane + idx];
+        }
+      }
     }
     __syncthreads();
     const int N = base;
@@ -141,37 +146,13 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
     }
 
     if (a.col_rwc >= 0) {
-      const int n2 = next_pow2(N);
-      // channel 1: sort, distinct-prefix, dense rank per pixel
-      for (int i = tid; i < n2; i += blockDim.x) S[i] = (i < N) ? fv[i] : INFINITY;
-      block_bitonic_sort(S, n2);
-      for (int i = tid; i < N; i += blockDim.x) P[i] = (i > 0 && S[i] != S[i - 1]) ? 1 : 0;
-      __syncthreads();
-      block_inclusive_scan(P, N, part);
-      const int R1MAX = P[N - 1];
-      for (int j = tid; j < N; j += blockDim.x) {
-        const float v = fv[j];
-        int lo = 0, hi = N;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] < v) lo = mid + 1; else hi = mid; }
-        r1[j] = P[lo];
-      }
-      __syncthreads();
-      // channel 2
-      for (int i = tid; i < n2; i += blockDim.x) S[i] = (i < N) ? sv[i] : INFINITY;
-      block_bitonic_sort(S, n2);
-      for (int i = tid; i < N; i += blockDim.x) P[i] = (i > 0 && S[i] != S[i - 1]) ? 1 : 0;
-      __syncthreads();
-      block_inclusive_scan(P, N, part);
-      const int R2MAX = P[N - 1];
-      const double R = (double)(max(R1MAX, R2MAX) + 1);
+      // dense ranks come from the per-channel rank planes (one sort per object and channel, shared by all pairs)
+      const double R = (double)(max(a.rmax[(size_t)oi * a.C + a.ch0], a.rmax[(size_t)oi * a.C + a.ch1]) + 1);
       double q[2] = {0, 0};
       for (int j = tid; j < N; j += blockDim.x) {
         const double f = fv[j], s = sv[j];
         if (f >= tff && s >= tss) {
-          const float v = sv[j];
-          int lo = 0, hi = N;
-          while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] < v) lo = mid + 1; else hi = mid; }
-          const int di = abs(r1[j] - P[lo]);
+          const long long di = llabs((long long)rk1[j] - (long long)rk2[j]);
           const double wgt = (R - (double)di) * 1.0 / R;
           q[0] += f * wgt; q[1] += s * wgt;
         }
@@ -261,12 +242,117 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
   }
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// dense per-object ranks of one channel: rank(p) = number of distinct values of the object smaller than
+// the value at p (CellProfiler's Rank_im: lexsort + cumsum of "value changed").  One sort per
+// (object, channel), written into a tile-shaped plane so that every channel pair reuses it.
+// -----------------------------------------------------------------------------------------------------
+struct RankArgs {
+  const u16* labels;
+  const void* planes;
+  int F, C, Y, X, channel;
+  const aliby_object* tab;
+  int n_obj, cap;
+  unsigned char* gscratch;
+  unsigned int* ranks;  // [F,C,Y,X]
+  int* rmax;            // [n_obj, C]
+};
+
+template <typename T, bool GLOBAL>
+__global__ __launch_bounds__(256) void k_ranks(RankArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ int wsum[4];
+  __shared__ int part[256];
+  unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * (size_t)a.cap * 16) : lds_raw;
+  float* vals = reinterpret_cast<float*>(ws);
+  float* S = vals + a.cap;
+  int* P = reinterpret_cast<int*>(S + a.cap);
+  int* pix = P + a.cap;
+  const int tid = threadIdx.x;
+  const size_t plane = (size_t)a.Y * a.X;
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    if (o.area <= 0) { if (tid == 0) a.rmax[(size_t)oi * a.C + a.channel] = 0; continue; }
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const T* px = reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.channel) * plane;
+    unsigned int* rk = a.ranks + ((size_t)o.tile * a.C + a.channel) * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, npix = h * w;
+    const u16 L = (u16)o.label;
+    __syncthreads();
+    int base = 0;
+    for (int i0 = 0; i0 < npix; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      bool in = false;
+      size_t idx = 0;
+      if (i < npix) { idx = (size_t)(o.y0 + i / w) * a.X + (o.x0 + i % w); in = lab[idx] == L; }
+      const int pos = block_compact_slot(in, base, wsum);
+      if (in) { vals[pos] = px_load<T>(px, idx); pix[pos] = (int)idx; }
+    }
+    __syncthreads();
+    const int N = base, n2 = next_pow2(N);
+    for (int i = tid; i < n2; i += blockDim.x) S[i] = (i < N) ? vals[i] : INFINITY;
+    block_bitonic_sort(S, n2);
+    for (int i = tid; i < N; i += blockDim.x) P[i] = (i > 0 && S[i] != S[i - 1]) ? 1 : 0;
+    __syncthreads();
+    block_inclusive_scan(P, N, part);
+    for (int j = tid; j < N; j += blockDim.x) {
+      const float v = vals[j];
+      int lo = 0, hi = N;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (S[mid] < v) lo = mid + 1; else hi = mid; }
+      rk[pix[j]] = (unsigned int)P[lo];
+    }
+    if (tid == 0) a.rmax[(size_t)oi * a.C + a.channel] = P[N - 1];
+    __syncthreads();
+  }
+}
+
+extern "C" int aliby_object_ranks(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
+                                  int Y, int X, int channel, const aliby_object* table_dev, int n_obj, int max_area,
+                                  uint32_t* ranks_dev, int32_t* rmax_dev, void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (n_obj == 0) return ALIBY_OK;
+  ARG_CHECK(labels && planes && table_dev && ranks_dev && rmax_dev, "NULL argument");
+  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
+  ARG_CHECK(channel >= 0 && channel < C, "channel out of range");
+  ARG_CHECK((size_t)Y * X < (size_t)INT_MAX, "plane too large");
+  RankArgs a;
+  a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.channel = channel; a.tab = table_dev;
+  a.n_obj = n_obj; a.ranks = ranks_dev; a.rmax = rmax_dev;
+  int cap = 64;
+  while (cap < max_area) cap <<= 1;
+  a.cap = cap;
+  hipStream_t s = as_stream(stream);
+  const size_t need = (size_t)cap * 16;
+  if (need <= 96 * 1024) {
+    a.gscratch = nullptr;
+    dim3 grid(n_obj), block(aliby_pick_block(max_area));
+    if (dtype == ALIBY_U16) {
+      if (need > 32 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_ranks<u16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_ranks<u16, false>), grid, block, need, s, a);
+    } else {
+      if (need > 32 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_ranks<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
+      hipLaunchKernelGGL((k_ranks<float, false>), grid, block, need, s, a);
+    }
+  } else {
+    const int g = n_obj < 512 ? n_obj : 512;
+    int rc = aliby_ensure_scratch(ctx, (size_t)g * need);
+    if (rc) return rc;
+    a.gscratch = (unsigned char*)ctx->scratch;
+    dim3 grid(g), block(256);
+    if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_ranks<u16, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_ranks<float, true>), grid, block, 0, s, a);
+  }
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
 extern "C" int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
                                     int F, int C, int Y, int X, int ch0, int ch1,
                                     const aliby_object* table_dev, int n_obj, int max_area,
                                     double* out, int ld, int col_pearson, int col_manders, int col_rwc,
                                     int col_costes, double thr_percent, double costes_scale_max,
-                                    void* stream) {
+                                    const uint32_t* ranks_dev, const int32_t* rmax_dev, void* stream) {
   ARG_CHECK(ctx != nullptr, "ctx is NULL");
   if (n_obj == 0) return ALIBY_OK;
   ARG_CHECK(labels && planes && table_dev && out, "NULL argument");
@@ -280,11 +366,13 @@ extern "C" int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, cons
   a.tab = table_dev; a.n_obj = n_obj; a.out = out; a.ld = ld;
   a.col_pearson = col_pearson; a.col_manders = col_manders; a.col_rwc = col_rwc; a.col_costes = col_costes;
   a.thr = thr_percent; a.scale_max = costes_scale_max;
+  a.ranks = ranks_dev; a.rmax = rmax_dev;
+  ARG_CHECK(col_rwc < 0 || (ranks_dev && rmax_dev), "rwc needs the rank planes (aliby_object_ranks)");
   int cap = 64;
   while (cap < max_area) cap <<= 1;
   a.cap = cap;
   hipStream_t s = as_stream(stream);
-  const size_t need = (size_t)cap * 20;
+  const size_t need = (size_t)cap * 16;
   if (need <= 96 * 1024) {
     a.gscratch = nullptr;
     dim3 grid(n_obj), block(aliby_pick_block(max_area));

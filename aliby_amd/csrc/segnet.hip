@@ -12,34 +12,68 @@
 
 typedef unsigned short u16;
 
-// ---- histogram ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hist_u16(const u16* __restrict__ img, size_t plane, int* __restrict__ hist) {
-  const int f = blockIdx.y;
-  const u16* p = img + (size_t)f * plane;
-  int* h = hist + (size_t)f * 65536;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x)
-    atomicAdd(&h[p[i]], 1);
+// ---- exact percentiles by two-pass radix select -----------------------------------------------------
+// Pass 1: 256-bin histogram of the HIGH byte (LDS-privatised, equal keys of a wave merged with ballots —
+// a fluorescence background puts most pixels of a wave in one bin).  k_pick_buckets locates the (at most 4)
+// buckets holding ranks floor(pos), floor(pos)+1 of both percentiles.  Pass 2: 256-bin histogram of the LOW
+// byte inside those buckets.  k_percentiles_radix reads the order statistics and interpolates like
+// numpy.percentile(method="linear").
+struct alignas(16) u16x8s { u16 v[8]; };
+
+__device__ __forceinline__ void wave_hist_add(int* h, int key, bool valid) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long active = __ballot(valid);
+  while (active) {
+    const int lead = __ffsll((long long)active) - 1;
+    const int k = __shfl(key, lead, 64);
+    const unsigned long long m = __ballot(valid && key == k);
+    if (lane == lead) atomicAdd(&h[k], (int)__popcll(m));
+    active &= ~m;
+  }
 }
 
-// one workgroup (1024 threads) per image: cumulative histogram -> order statistics -> percentiles
-__global__ __launch_bounds__(1024) void k_percentiles(const int* __restrict__ hist, size_t plane, double qlo, double qhi,
-                                                      double* __restrict__ out) {
-  __shared__ long long part[1024];
-  __shared__ double vals[4];
-  const int f = blockIdx.x, t = threadIdx.x;
-  const int* h = hist + (size_t)f * 65536;
-  long long c = 0;
-  for (int k = 0; k < 64; ++k) c += h[t * 64 + k];
-  part[t] = c;
+__global__ __launch_bounds__(256) void k_hist_hi(const u16* __restrict__ img, size_t plane, int* __restrict__ hist_hi) {
+  __shared__ int h[256];
+  const int f = blockIdx.y;
+  const u16* p = img + (size_t)f * plane;
+  h[threadIdx.x] = 0;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const long long v = (t >= o) ? part[t - o] : 0;
+  const size_t nvec = plane / 8;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < (aligned ? nvec : 0); i0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = i0 + threadIdx.x;
+    u16x8s v;
+    const bool ok = i < nvec;
+    if (ok) v = *reinterpret_cast<const u16x8s*>(p + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wave_hist_add(h, ok ? (v.v[k] >> 8) : 0, ok);
+  }
+  const size_t tail0 = aligned ? nvec * 8 : 0;
+  for (size_t i0 = tail0 + (size_t)blockIdx.x * blockDim.x; i0 < plane; i0 += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = i0 + threadIdx.x;
+    const bool ok = i < plane;
+    wave_hist_add(h, ok ? (p[i] >> 8) : 0, ok);
+  }
+  __syncthreads();
+  const int c = h[threadIdx.x];
+  if (c) atomicAdd(&hist_hi[f * 256 + threadIdx.x], c);
+}
+
+// one workgroup (256 threads) per image: prefix of the high-byte histogram -> buckets of the 4 wanted ranks
+__global__ __launch_bounds__(256) void k_pick_buckets(const int* __restrict__ hist_hi, size_t plane, double qlo, double qhi,
+                                                      int* __restrict__ bucket, long long* __restrict__ before) {
+  __shared__ long long pre[256];
+  const int f = blockIdx.x, t = threadIdx.x;
+  const long long c = hist_hi[f * 256 + t];
+  pre[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const long long v = (t >= o) ? pre[t - o] : 0;
     __syncthreads();
-    part[t] += v;
+    pre[t] += v;
     __syncthreads();
   }
-  const long long before = part[t] - c;  // pixels with value < t*64
-  // ranks wanted: floor(pos) and floor(pos)+1 for both percentiles
+  const long long b4 = pre[t] - c;
   const double n1 = (double)(plane - 1);
   const double pos[2] = {n1 * (qlo / 100.0), n1 * (qhi / 100.0)};
   for (int q = 0; q < 2; ++q) {
@@ -47,24 +81,59 @@ __global__ __launch_bounds__(1024) void k_percentiles(const int* __restrict__ hi
     long long hi = lo + 1;
     if (hi > (long long)plane - 1) hi = (long long)plane - 1;
     const long long want[2] = {lo, hi};
-    for (int w = 0; w < 2; ++w) {
-      const long long r = want[w];
-      if (r >= before && r < before + c) {
-        long long run = before;
-        for (int k = 0; k < 64; ++k) {
-          run += h[t * 64 + k];
-          if (r < run) { vals[q * 2 + w] = (double)(t * 64 + k); break; }
-        }
-      }
-    }
+    for (int w = 0; w < 2; ++w)
+      if (c > 0 && want[w] >= b4 && want[w] < b4 + c) { bucket[f * 4 + q * 2 + w] = t; before[f * 4 + q * 2 + w] = b4; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_hist_lo(const u16* __restrict__ img, size_t plane, const int* __restrict__ bucket,
+                                                 int* __restrict__ hist_lo) {
+  __shared__ int h[4 * 256];
+  const int f = blockIdx.y;
+  const u16* p = img + (size_t)f * plane;
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) h[i] = 0;
+  int b[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b[k] = bucket[f * 4 + k];
+  // duplicates among the 4 buckets are served by the first slot holding that bucket
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = p[i], hb = v >> 8;
+    int slot = -1;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) if (hb == b[k]) slot = k;
+    if (slot >= 0) atomicAdd(&h[slot * 256 + (v & 255)], 1);
   }
   __syncthreads();
-  if (t == 0) {
-    for (int q = 0; q < 2; ++q) {
-      const double a = vals[q * 2], b = vals[q * 2 + 1];
-      const double tt = pos[q] - floor(pos[q]);
-      out[f * 2 + q] = a + (b - a) * tt;
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) { const int c = h[i]; if (c) atomicAdd(&hist_lo[f * 1024 + i], c); }
+}
+
+__global__ __launch_bounds__(64) void k_percentiles_radix(const int* __restrict__ hist_lo, const int* __restrict__ bucket,
+                                                          const long long* __restrict__ before, size_t plane, double qlo,
+                                                          double qhi, double* __restrict__ out) {
+  const int f = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const double n1 = (double)(plane - 1);
+  const double pos[2] = {n1 * (qlo / 100.0), n1 * (qhi / 100.0)};
+  double vals[4];
+  for (int q = 0; q < 2; ++q) {
+    const long long lo = (long long)floor(pos[q]);
+    long long hi = lo + 1;
+    if (hi > (long long)plane - 1) hi = (long long)plane - 1;
+    const long long want[2] = {lo, hi};
+    for (int w = 0; w < 2; ++w) {
+      const int k = q * 2 + w, bk = bucket[f * 4 + k];
+      int slot = k;
+      for (int j = 3; j >= 0; --j) if (bucket[f * 4 + j] == bk) slot = j;  // first slot holding this bucket
+      long long run = before[f * 4 + k];
+      int low = 255;
+      for (int j = 0; j < 256; ++j) { run += hist_lo[f * 1024 + slot * 256 + j]; if (want[w] < run) { low = j; break; } }
+      vals[k] = (double)((bk << 8) | low);
     }
+  }
+  for (int q = 0; q < 2; ++q) {
+    const double a = vals[q * 2], b = vals[q * 2 + 1], tt = pos[q] - floor(pos[q]);
+    out[f * 2 + q] = a + (b - a) * tt;
   }
 }
 
@@ -182,16 +251,27 @@ int aliby_normalize99_u16(aliby_ctx* ctx, const uint16_t* img, int F, int Y, int
   if (F == 0) return ALIBY_OK;
   ARG_CHECK(img && out && percentiles_dev, "NULL argument");
   const size_t plane = (size_t)Y * X;
-  int rc = aliby_ensure_scratch(ctx, sizeof(int) * 65536 * (size_t)F);
+  // scratch: hist_hi int[F*256] | hist_lo int[F*1024] | bucket int[F*4] | before i64[F*4]
+  const size_t b_hi = sizeof(int) * 256 * (size_t)F, b_lo = sizeof(int) * 1024 * (size_t)F, b_bk = sizeof(int) * 4 * (size_t)F;
+  const size_t b_bf = sizeof(long long) * 4 * (size_t)F;
+  int rc = aliby_ensure_scratch(ctx, b_hi + b_lo + ((b_bk + 15) & ~(size_t)15) + b_bf);
   if (rc) return rc;
   hipStream_t s = as_stream(stream);
-  int* hist = (int*)ctx->scratch;
-  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(int) * 65536 * (size_t)F, s));
-  int bx = (int)((plane + 255) / 256);
-  if (bx > 512) bx = 512;
-  hipLaunchKernelGGL(k_hist_u16, dim3(bx, F), dim3(256), 0, s, img, plane, hist);
+  int* hist_hi = (int*)ctx->scratch;
+  int* hist_lo = hist_hi + 256 * (size_t)F;
+  int* bucket = hist_lo + 1024 * (size_t)F;
+  long long* before = (long long*)((unsigned char*)ctx->scratch + b_hi + b_lo + ((b_bk + 15) & ~(size_t)15));
+  HIP_TRY(hipMemsetAsync(hist_hi, 0, b_hi + b_lo, s));
+  int bx = (int)((plane / 8 + 255) / 256);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_hist_hi, dim3(bx, F), dim3(256), 0, s, img, plane, hist_hi);
   KERNEL_CHECK();
-  hipLaunchKernelGGL(k_percentiles, dim3(F), dim3(1024), 0, s, hist, plane, lower, upper, percentiles_dev);
+  hipLaunchKernelGGL(k_pick_buckets, dim3(F), dim3(256), 0, s, hist_hi, plane, lower, upper, bucket, before);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_hist_lo, dim3(bx, F), dim3(256), 0, s, img, plane, bucket, hist_lo);
+  KERNEL_CHECK();
+  hipLaunchKernelGGL(k_percentiles_radix, dim3(F), dim3(64), 0, s, hist_lo, bucket, before, plane, lower, upper, percentiles_dev);
   KERNEL_CHECK();
   hipLaunchKernelGGL(k_normalize99, dim3(grid_for(plane * F)), dim3(256), 0, s, img, plane, F, percentiles_dev, out);
   KERNEL_CHECK();

@@ -292,15 +292,39 @@ class FeatureEngine:
             )
         return out
 
+    def rank_planes(self, labels, planes, dtype, table: ObjectTable, channels):
+        """uint32 [F,C,Y,X] dense ranks + int32 [n_obj,C] maxima for `channels`, cached on the table per plane tensor."""
+        F, Cn, Y, X = planes.shape
+        key = ("ranks", planes.data_ptr())
+        cache = table.__dict__.setdefault("_ranks", {})
+        if key not in cache:
+            cache[key] = dict(ranks=torch.empty((F, Cn, Y, X), dtype=torch.int32, device=planes.device),
+                              rmax=torch.zeros((max(table.n_obj, 1), Cn), dtype=torch.int32, device=planes.device), done=set())
+        e = cache[key]
+        for ch in channels:
+            if ch in e["done"]:
+                continue
+            with self.timed("ranks"):
+                _lib.check(self.lib.aliby_object_ranks(self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch),
+                                                       _ptr(table.dev), table.n_obj, table.max_area, _ptr(e["ranks"]),
+                                                       _ptr(e["rmax"]), _stream_ptr()))
+            e["done"].add(ch)
+        return e["ranks"], e["rmax"]
+
     def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
         """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
         F, Cn, Y, X = planes.shape
         c = lambda k: -1 if cols.get(k) is None else int(cols[k])  # noqa: E731
+        ranks = rmax = None
+        if cols.get("rwc") is not None:
+            ranks, rmax = self.rank_planes(labels, planes, dtype, table, (ch0, ch1))
         with self.timed("coloc"):
             _lib.check(
                 self.lib.aliby_features_coloc(
                     self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch0), int(ch1),
                     _ptr(table.dev), table.n_obj, table.max_area, _ptr(out), out.stride(0), c("pearson"),
-                    c("manders_fold"), c("rwc"), c("costes"), float(thr), float(scale_max), _stream_ptr(),
+                    c("manders_fold"), c("rwc"), c("costes"), float(thr), float(scale_max),
+                    _ptr(ranks) if ranks is not None else 0, _ptr(rmax) if rmax is not None else 0, _stream_ptr(),
                 )
             )
+

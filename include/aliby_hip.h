@@ -233,12 +233,20 @@ int aliby_features_cell(aliby_ctx* ctx, const uint16_t* labels, const void* plan
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the
  * channel pair (ch0, ch1); col_* is the first of the metric's two columns or -1 to skip it.
- * thr_percent = 15 and costes_scale_max = 255 are CellProfiler's defaults. */
+ * thr_percent = 15 and costes_scale_max = 255 are CellProfiler's defaults.  rwc needs ranks_dev / rmax_dev
+ * (aliby_object_ranks) for both channels; they may be NULL otherwise. */
 int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
                          int F, int C, int Y, int X, int ch0, int ch1,
                          const aliby_object* table_dev, int n_obj, int max_area,
                          double* out, int ld, int col_pearson, int col_manders, int col_rwc,
-                         int col_costes, double thr_percent, double costes_scale_max, void* stream);
+                         int col_costes, double thr_percent, double costes_scale_max,
+                         const uint32_t* ranks_dev, const int32_t* rmax_dev, void* stream);
+/* Dense per-object ranks of one channel (CellProfiler's Rank_im of the RWC coefficient): ranks_dev
+ * [F,C,Y,X] uint32 receives, at every object pixel, the number of distinct smaller values of that object in
+ * `channel`; rmax_dev [n_obj, C] the largest rank.  One sort per (object, channel), shared by all pairs. */
+int aliby_object_ranks(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
+                       int Y, int X, int channel, const aliby_object* table_dev, int n_obj, int max_area,
+                       uint32_t* ranks_dev, int32_t* rmax_dev, void* stream);
 
 #ifdef __cplusplus
 }
