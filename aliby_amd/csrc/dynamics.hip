@@ -60,17 +60,30 @@ __device__ __forceinline__ float tap(const float* __restrict__ f, int yy, int xx
 // foreground pixels (cellprob > thr) compacted into a list so that flow following runs on full waves: only
 // ~10-35 % of the pixels are foreground and each follows 200 dependent steps.  Wave-aggregated append; the
 // list order is irrelevant (every pixel is independent, the histogram is integer).
+#define FG_CHUNK 4096  // pixels per workgroup pass: one global atomic per 4096 pixels instead of one per wave
 __global__ __launch_bounds__(256) void k_compact_fg(const float* __restrict__ prob, float thr, size_t total,
                                                     int* __restrict__ list, int* __restrict__ count) {
-  for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < total; i0 += (size_t)gridDim.x * blockDim.x) {
-    const size_t i = i0 + threadIdx.x;
-    const bool fg = i < total && prob[i] > thr;
-    const unsigned long long bal = __ballot(fg);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && bal) base = atomicAdd(count, __popcll(bal));
-    base = __shfl(base, 0, 64);
-    if (fg) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int)i;
+  __shared__ int red_i[8];
+  __shared__ int wsum[4];
+  __shared__ int s_base;
+  for (size_t c0 = (size_t)blockIdx.x * FG_CHUNK; c0 < total; c0 += (size_t)gridDim.x * FG_CHUNK) {
+    int n = 0;
+    for (int k = 0; k < FG_CHUNK / 256; ++k) {
+      const size_t i = c0 + (size_t)k * 256 + threadIdx.x;
+      n += (i < total && prob[i] > thr) ? 1 : 0;
+    }
+    const int tot = block_sum_i32(n, red_i);
+    if (tot == 0) continue;  // block-uniform
+    if (threadIdx.x == 0) s_base = atomicAdd(count, tot);
+    __syncthreads();
+    int base = s_base;
+    for (int k = 0; k < FG_CHUNK / 256; ++k) {
+      const size_t i = c0 + (size_t)k * 256 + threadIdx.x;
+      const bool fg = i < total && prob[i] > thr;
+      const int pos = block_compact_slot(fg, base, wsum);
+      if (fg) list[pos] = (int)i;
+    }
+    __syncthreads();
   }
 }
 

@@ -116,3 +116,88 @@ def test_default_builder_pipeline_runs_all_families(tmp_path, engine):
                 "0/max/radial_distribution/RadialDistribution_FracAtD_1of4",
                 "1/max/radial_zernikes/RadialDistribution_ZernikePhase_2_2", "None/None/sizeshape/Area"):
         assert key in cols, key
+
+
+def test_timelapse_zstack_pipeline_config4_like(tmp_path, engine):
+    """Config-4-like (BASELINE.json configs[3]): T time points, Z=5, one channel, monotile; every tp is tiled,
+    segmented, written and measured; profiles carry metadata_tp; retain trims the history
+    (pipe_core.py:245-249)."""
+    import torch
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.extraction.extract import format_extraction
+    from oracle import aliby_extract as ox
+    from oracle import cellpose_restated as cr
+
+    T = 3
+    fovs = [synth.make_fov(4, t, shape=(160, 192), n_channels=1, n_z=5, n_target=8 + 2 * t) for t in range(T)]
+    tczyx = np.stack([f["pixels"] for f in fovs])  # [T,1,5,Y,X]
+    flows = [synth.analytic_flows(f["nuclei"]) for f in fovs]
+    calls = {"n": 0}
+
+    def override(x):
+        t = calls["n"]
+        calls["n"] += 1
+        return torch.from_numpy(flows[t][0][None]).cuda(), torch.from_numpy(flows[t][1][None]).cuda()
+
+    tree = {"None": {"None": ["sizeshape"]}, 0: {"max": ["intensity"]}}
+    pipeline = {
+        "ntps": T,
+        "steps": {
+            "tile": {"image_kwargs": {"source": tczyx}, "tile_size": None},
+            "segment_cells": {"segmenter_kwargs": {"kind": "cellpose", "setup_params": {"flows_override": override}},
+                              "channel_to_segment": 0},
+            "extract_cells": {"tree": tree},
+        },
+        "passed_data": {"extract_cells": [("masks", "segment_cells"), ("pixels", "tile")]},
+        "passed_methods": {"segment_cells": ("tile", "get_fczyx")},
+        "save": ("segment_cells",),
+        "save_interval": 1,
+        "retain": {"tile": 1},
+    }
+    profiles, _ = run_pipeline_and_post(pipeline=pipeline, pipeline_name="pos001", output_path=tmp_path)
+    assert calls["n"] == T
+    got = profiles.to_pandas()
+    assert sorted(got["metadata_tp"].unique().tolist()) == list(range(T))
+    for t in range(T):
+        want_mask = cr.finish_labels(cr.compute_masks(*flows[t]))
+        with np.load(tmp_path / "steps" / "pos001" / "segment_cells" / f"{t:04d}.npz") as z:
+            assert np.array_equal(z["arr_0"], want_mask)
+        want = format_extraction(ox.process_tree_masks(tree, want_mask, tczyx[t][None], ox.extract_tree)).to_pandas()
+        sub = got[got["metadata_tp"] == t].sort_values("metadata_label")
+        assert len(sub) == len(want) == int(want_mask.max())
+        for col in want.columns:
+            if col in ("tile", "label") or col.endswith("Orientation"):
+                continue
+            assert np.allclose(sub[col].to_numpy(float), want[col].to_numpy(float), rtol=1e-4, atol=1e-8, equal_nan=True), (t, col)
+
+
+def test_deep_zstack_projection_config5_like(engine):
+    """Config-5-like (BASELINE.json configs[4]): Z=32, 2 channels.  As wired by the reference, pixels are
+    max-projected for segmentation (dispatch.py:199-206) and for every feature ("max" reducer), so the
+    reference-faithful result is 2-D; true 3-D features are beyond the reference (SURVEY.md §8d, C5 note)."""
+    import torch
+    from aliby_amd.extraction.extract import extract_tree, process_tree_masks
+    from aliby_amd.segment.dispatch import dispatch_segmenter
+    from oracle import aliby_extract as ox
+    from oracle import cellpose_restated as cr
+
+    f = synth.make_fov(5, 0, shape=(128, 160), n_channels=2, n_z=32, n_target=8)
+    dP, prob = synth.analytic_flows(f["nuclei"])
+    seen = {}
+
+    def override(x):
+        seen["x"] = x.cpu().numpy()
+        return torch.from_numpy(dP[None]).cuda(), torch.from_numpy(prob[None]).cuda()
+
+    segment = dispatch_segmenter(kind="cellpose", channel_to_segment=0, setup_params=dict(flows_override=override))
+    pixels = f["pixels"][None]  # [1,2,32,Y,X]
+    labels = segment(pixels)
+    assert np.array_equal(seen["x"][0], pixels[0, 0].max(axis=0))
+    assert np.array_equal(labels, cr.finish_labels(cr.compute_masks(dP, prob)))
+    tree = {1: {"max": ["intensity", "radial_distribution"]}, 0: {"add": ["intensity"]}}
+    inst, res = process_tree_masks(tree, labels, pixels, extract_tree)
+    inst_o, res_o = ox.process_tree_masks(tree, labels, pixels, ox.extract_tree)
+    assert inst == inst_o
+    for a, b in zip(res, res_o):
+        for k in b:
+            assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-8, equal_nan=True), k
