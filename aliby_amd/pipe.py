@@ -11,47 +11,42 @@ from __future__ import annotations
 from functools import partial
 from typing import Callable
 
-from aliby_amd.pipe_core import (
-    _init_extract,
-    _init_extract_multi,
-    _init_nahual,
-    _init_tile,
-    _run_pipeline_and_post_impl,
-)
+from aliby_amd import pipe_core as core
 from aliby_amd.segment.dispatch import dispatch_segmenter
 
 
-def _init_segment_cellpose(step_name: str, parameters: dict, other_steps: dict) -> Callable:
-    seg_kwargs = parameters.get("segmenter_kwargs", {})
-    if "channel_to_segment" not in parameters:
+def _segmenter(step_name: str, parameters: dict, _initialised: dict) -> Callable:
+    """Cellpose on the HIP path; `segmenter_kwargs` go to the dispatcher untouched."""
+    channel = parameters.get("channel_to_segment", parameters)
+    if channel is parameters:
         raise ValueError(f"Step '{step_name}' is missing required 'channel_to_segment'.")
-    return dispatch_segmenter(channel_to_segment=parameters["channel_to_segment"], **seg_kwargs)
+    return dispatch_segmenter(channel_to_segment=channel, **parameters.get("segmenter_kwargs", {}))
 
 
-def _init_track_cellpose(step_name: str, parameters: dict, other_steps: dict) -> Callable:
+def _tracker(step_name: str, parameters: dict, _initialised: dict) -> Callable:
     raise NotImplementedError(
         "the reference's 'stitch' tracker is broken/deprecated (src/aliby/track/trackers.py:11,75,87; SURVEY §2 row 15)"
     )
 
 
+# first matching prefix wins, in the reference's order (pipe.py:56-72)
 _PREFIXES = (
-    ("tile", lambda s, p, o: _init_tile(s, p)),
-    ("segment", _init_segment_cellpose),
-    ("track", _init_track_cellpose),
-    ("extract_", lambda s, p, o: _init_extract(s, p, overlap=False)),
-    ("extractmulti_", lambda s, p, o: _init_extract_multi(s, p)),
-    ("nahual_embed", lambda s, p, o: _init_nahual(s, p)),
-    ("nahual_track", lambda s, p, o: _init_nahual(s, p)),
+    ("tile", lambda name, params, done: core._init_tile(name, params)),
+    ("segment", _segmenter),
+    ("track", _tracker),
+    ("extract_", lambda name, params, done: core._init_extract(name, params, overlap=False)),
+    ("extractmulti_", lambda name, params, done: core._init_extract_multi(name, params)),
+    ("nahual_embed", lambda name, params, done: core._init_nahual(name, params)),
+    ("nahual_track", lambda name, params, done: core._init_nahual(name, params)),
 )
 
 
 def init_step(step_name: str, parameters: dict, other_steps: dict | None = None) -> Callable:
-    """Set up any step of the cellpose pipeline; first matching prefix wins (pipe.py:56-72)."""
-    other_steps = {} if other_steps is None else other_steps
-    for prefix, init in _PREFIXES:
+    """Set up any step of the cellpose pipeline from its name prefix."""
+    for prefix, make in _PREFIXES:
         if step_name.startswith(prefix):
-            return init(step_name, parameters, other_steps)
+            return make(step_name, parameters, other_steps or {})
     raise ValueError(f"Invalid step name {step_name=}")
 
 
-run_pipeline_and_post = partial(_run_pipeline_and_post_impl, init_step_fn=init_step, post_state_hook=None)
+run_pipeline_and_post = partial(core._run_pipeline_and_post_impl, init_step_fn=init_step, post_state_hook=None)
