@@ -1,0 +1,339 @@
+// nn_conv.hip — the U-Net's 3x3 convolution unit as ONE hand-written MFMA kernel (bf16, NHWC).
+//
+// Every convolution unit of the Cellpose residual U-Net (reference call site: cellpose's CPnet as driven by
+// src/aliby/segment/dispatch.py:55-63) is   BatchNorm -> ReLU -> Conv3x3 (+ bias) (+ residual / skip add).
+// At the two high-resolution levels (32 / 64 channels) that work is HBM-bound (144-288 FLOP/B against a
+// machine balance of ~500), so the pointwise stages must not cost their own passes over HBM.  This kernel
+// fuses them around an implicit GEMM on the matrix cores:
+//
+//   prologue  a = bf16( relu( scale[c] * IN[n, y>>UP, x>>UP, c] + shift[n, c] ) ), zero outside the image
+//             staged ONCE per workgroup tile into LDS as 16-byte channel-octet planes [octet][row][col]
+//   GEMM      D[cout, pixel] += Wt[cout, (tap, c)] * a[(tap, c), pixel]   v_mfma_f32_32x32x16_bf16,
+//             the packed weights of the wave's 32 output channels live in VGPRs for the whole launch
+//             (persistent workgroups), the pixel operand is one conflict-free ds_read_b128 per MFMA
+//   epilogue  OUT = bf16( D + bias[cout] + RES[n, y>>RU, x>>RU, cout] )  written as 32-byte runs per lane
+//
+// Operand roles: the weights are the MFMA "A" operand (row m = output channel) and the pixels the "B"
+// operand (column n = pixel), so that a lane ends up with 16 output channels of ONE pixel; the row order of
+// the weights is permuted at pack time so that those 16 channels are contiguous in memory
+// (MFMA row (reg&3) + 8*(reg>>2) + 4*(lane>>5)  <->  channel 16*(lane>>5) + reg).
+#include "common.h"
+#include <utility>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+namespace {
+
+// compile-time loop: every index is a constant expression, so register arrays are never indexed dynamically
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ float cv_bf2f(unsigned h) { return __uint_as_float(h << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned cv_pack2(float lo, float hi) {
+  const f32x2_t f = {lo, hi};
+  const bf16x2_t b = __builtin_convertvector(f, bf16x2_t);
+  return __builtin_bit_cast(unsigned, b);
+}
+__device__ __forceinline__ unsigned cv_f2bf(float f) { return cv_pack2(f, 0.f) & 0xffffu; }
+
+struct ConvArgs {
+  const uint4* in;     // [N, H>>UP, W>>UP, CIN] bf16
+  const uint4* wpk;    // packed weights, see k_pack_conv3x3
+  uint4* out;          // [N, H, W, COUT] bf16
+  const float* scale;  // [CIN]
+  const float* shift;  // [N, CIN] (shift_stride = CIN) or [CIN] (shift_stride = 0)
+  const float* bias;   // [COUT] or NULL
+  const uint4* res;    // [N, H>>res_up, W>>res_up, COUT] bf16 or NULL
+  int shift_stride, res_up;
+  int N, H, W;
+  int tiles_x, tiles_y, ntiles;
+};
+
+template <int CIN, int COUT>
+struct ConvCfg {
+  static constexpr int KC = CIN / 16;    // MFMA k-steps per tap
+  static constexpr int NPL = CIN / 8;    // 16-byte channel-octet planes in LDS
+  static constexpr int NCB = COUT / 32;  // blocks of 32 output channels
+  // register budget per wave (256 VGPRs at 2 waves/SIMD): 9*KC*4 for the weights + 16*R accumulators
+  // + the next tile's staging loads + the residual prefetch
+  static constexpr int R = CIN >= 64 ? 2 : 4;                      // output rows per wave and pass
+  static constexpr int PASSES = (CIN >= 64 && COUT >= 64) ? 2 : 1; // row passes per tile (accumulators reused)
+  static constexpr int RG = 4 / NCB;                               // row groups per workgroup (4 waves)
+  static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2;
+  static constexpr int RAW = LH * LW;
+  // plane pitch in 16-byte slots, chosen so that the 8-lane groups of ds_write_b128 (lanes = NPL octets x
+  // 8/NPL pixels) land on 8 distinct slots of the 128-byte bank window
+  static constexpr int PLANE = NPL == 4 ? RAW + (10 - RAW % 8) % 8 : (RAW | 1);
+  static constexpr int LDS_BYTES = NPL * PLANE * 16;
+  static constexpr int PIX_PER_IT = 256 / NPL;
+  static constexpr int ITERS = (RAW + PIX_PER_IT - 1) / PIX_PER_IT;  // staging loads per thread and tile
+  static constexpr int BATCH = CIN >= 64 ? (ITERS + 1) / 2 : ITERS;  // staging loads in flight per thread
+  // residual rows requested before the prologue (hidden behind it) when the registers allow, else per pass
+  static constexpr bool RES_EARLY = CIN < 64;
+  static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;  // pixel fragments in flight LDS -> VGPR ahead of their MFMAs
+};
+
+template <int CIN, int COUT, bool UP>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
+  using cfg = ConvCfg<CIN, COUT>;
+  constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
+  constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, PASSES = cfg::PASSES;
+  constexpr int PIX_PER_IT = cfg::PIX_PER_IT, ITERS = cfg::ITERS, BATCH = cfg::BATCH;
+  extern __shared__ uint4 lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = wave % NCB, rg = wave / NCB;
+  const int px = lane & 31, hh = lane >> 5;
+
+  // ---- weights of this wave's 32 output channels: 9*KC fragments, resident for the whole launch
+  bf16x8_t wfrag[9 * KC];
+  {
+    const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(a.wpk) + (size_t)cb * 9 * KC * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 9 * KC; ++i) wfrag[i] = wp[i * 64];
+  }
+  // ---- staging role of this thread: a fixed channel octet
+  const int pl = tid % NPL, pix0 = tid / NPL;
+  float sc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sc[k] = a.scale[pl * 8 + k];
+
+  const int IH = UP ? a.H >> 1 : a.H, IW = UP ? a.W >> 1 : a.W;
+  // XCD-aware persistent schedule: workgroup b lives on XCD b%8; each XCD walks one contiguous eighth of
+  // the tile list so that neighbouring tiles (shared halos) meet in the same L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  const int t_end = min(a.ntiles, (xcd + 1) * per_xcd);
+
+  for (int tile = xcd * per_xcd + slot; tile < t_end; tile += nslots) {
+    const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+    const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    float sh[8];
+    {
+      const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[k] = sp[k];
+    }
+    // ---- residual rows and bias seed the accumulators: requested now, unpacked after the prologue
+    const int gx = x0 + px;
+    const int c0 = cb * 32 + hh * 16;
+    uint4 rr[PASSES * R][2];
+    auto load_res = [&](int pass) {  // clamped: rows / columns past the image edge are never stored
+      const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
+      const uint4* resN = a.res + (size_t)n * RH * RW * (COUT / 8);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int cy = min(y0 + (rg * PASSES + pass) * R + r, a.H - 1), cx = min(gx, a.W - 1);
+        const unsigned off = (unsigned)(((cy >> a.res_up) * RW + (cx >> a.res_up)) * (COUT / 8) + (c0 >> 3));
+        rr[pass * R + r][0] = resN[off];
+        rr[pass * R + r][1] = resN[off + 1];
+      }
+    };
+    if (cfg::RES_EARLY && a.res) {
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) load_res(pass);
+    }
+    __syncthreads();  // every wave is done reading the previous tile's planes
+    // ---- stage the raw window: BATCH 16-byte loads per thread in flight at once (unconditional, from clamped
+    // addresses: no divergent branch around a load), then the prologue (BatchNorm affine + style shift + ReLU,
+    // bf16; the convolution's zero padding is applied AFTER the activation) into the LDS planes
+    const uint4* inN = a.in + (size_t)n * IH * IW * NPL;  // uniform base (SGPR pair) + 32-bit lane offsets
+    int p0 = pix0;
+    asm volatile("" : "+v"(p0));  // recompute the window coordinates per tile instead of keeping 2*ITERS registers
+#pragma unroll
+    for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+      uint4 v[BATCH];
+      unsigned inside = 0;
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (it0 + u >= ITERS) break;
+        const int pix = p0 + (it0 + u) * PIX_PER_IT;
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
+        inside |= (unsigned)(pix < RAW && gy >= 0 && gy < a.H && gxi >= 0 && gxi < a.W) << u;
+        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gxi, 0), a.W - 1);
+        v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * NPL + pl)];
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (it0 + u >= ITERS) break;
+        const int pix = p0 + (it0 + u) * PIX_PER_IT;
+        const unsigned keep = 0u - ((inside >> u) & 1u);  // all ones inside the image, zero in the padding
+        const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        unsigned r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float f0 = fmaxf(sc[2 * q] * cv_bf2f(w4[q] & 0xffffu) + sh[2 * q], 0.f);
+          const float f1 = fmaxf(sc[2 * q + 1] * cv_bf2f(w4[q] >> 16) + sh[2 * q + 1], 0.f);
+          r4[q] = cv_pack2(f0, f1) & keep;
+        }
+        if (it0 + u == ITERS - 1 && pix >= RAW) continue;  // only the last round can run past the window
+        lds[pl * PLANE + pix] = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+      }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int rbase = (rg * PASSES + pass) * R;  // first output row of this wave and pass inside the tile
+      f32x16_t acc[R];
+      if (!cfg::RES_EARLY && a.res) load_res(pass);
+      {
+        float4 b4[4] = {};
+        if (a.bias) {
+          const float4* bp = reinterpret_cast<const float4*>(a.bias + c0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (a.res) {
+          const uint4 r0 = rr[pass * R + r][0], r1 = rr[pass * R + r][1];
+          const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
+            acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- implicit GEMM.  A pixel fragment (input row ir, column offset dx, k-step kc) serves the up to three
+      // output rows r = ir - dy it is a tap of, so it is read from LDS once: (R+2)*3*KC ds_read_b128 for
+      // 9*KC*R MFMAs.  The reads run DEPTH fragments ahead of their MFMAs through a register ring; the
+      // sched_barrier keeps the compiler from hoisting them further (register budget, see ConvCfg).
+      const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px;
+      constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
+      bf16x8_t ring[DEPTH];
+      auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
+#pragma unroll
+      for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
+      static_for<NF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
+        constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
+        static_for<3>([&](auto dc) {
+          constexpr int dy = decltype(dc)::value, r = ir - dy;
+          if constexpr (r >= 0 && r < R)
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // ---- epilogue: bf16, 32 contiguous bytes per lane and row
+      if (gx < a.W) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int gy = y0 + rbase + r;
+          if (gy >= a.H) continue;
+          uint4* op = a.out + (size_t)n * a.H * a.W * (COUT / 8) + (unsigned)((gy * a.W + gx) * (COUT / 8) + (c0 >> 3));
+          op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
+                             cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
+          op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
+                             cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
+        }
+      }
+    }
+  }
+}
+
+// Packed layout: [cout block cb][tap][k-step kc][lane][8 bf16]; lane l holds the MFMA A fragment
+// A[row m = l&31][k = 8*(l>>5) + j] = W[cb*32 + chan(m)][cin = 16*kc + 8*(l>>5) + j][tap], with
+// chan(m) = 16*((m>>2)&1) + (m&3) + 4*(m>>3) (see the header comment).
+__global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, unsigned short* out, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  size_t rest = i >> 9;
+  const int kcn = cin / 16;
+  const int kc = (int)(rest % kcn);
+  rest /= kcn;
+  const int tap = (int)(rest % 9), cb = (int)(rest / 9);
+  const int m = lane & 31, h = lane >> 5;
+  const int co = cb * 32 + 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
+  const int ci = 16 * kc + 8 * h + j;
+  float v = 0.f;
+  if (ci < cin_src && co < cout) v = w[((size_t)co * cin_src + ci) * 9 + tap];
+  out[i] = (unsigned short)cv_f2bf(v);
+}
+
+template <int CIN, int COUT, bool UP>
+int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
+  using cfg = ConvCfg<CIN, COUT>;
+  a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
+  a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
+  const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
+  ARG_CHECK(nt < INT_MAX, "conv3x3: too many tiles");
+  a.ntiles = (int)nt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
+    attr_done = true;
+  }
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int nslots = per_xcd < 64 ? per_xcd : 64;  // 2 workgroups per CU, 32 CUs per XCD
+  hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+}  // namespace
+
+extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                                     const float* shift, int shift_per_sample, const float* bias, const void* res,
+                                     int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
+                                     void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3: null argument");
+  ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3: empty shape");
+  ARG_CHECK(!in_up || ((H & 1) == 0 && (W & 1) == 0), "conv3x3: upsampled input needs even H, W");
+  ARG_CHECK(!res || !res_up || ((H & 1) == 0 && (W & 1) == 0), "conv3x3: upsampled residual needs even H, W");
+  ConvArgs a;
+  a.in = static_cast<const uint4*>(in);
+  a.wpk = static_cast<const uint4*>(wpk);
+  a.out = static_cast<uint4*>(out);
+  a.scale = scale;
+  a.shift = shift;
+  a.bias = bias;
+  a.res = static_cast<const uint4*>(res);
+  a.shift_stride = shift_per_sample ? CIN : 0;
+  a.res_up = res_up ? 1 : 0;
+  a.N = N; a.H = H; a.W = W;
+  if (CIN == 32 && COUT == 32 && !in_up) return launch_conv<32, 32, false>(ctx, a, stream);
+  if (CIN == 64 && COUT == 32 && in_up) return launch_conv<64, 32, true>(ctx, a, stream);
+  if (CIN == 64 && COUT == 64 && !in_up) return launch_conv<64, 64, false>(ctx, a, stream);
+  if (CIN == 32 && COUT == 64 && !in_up) return launch_conv<32, 64, false>(ctx, a, stream);
+  aliby_set_error("conv3x3: unsupported (CIN=%d, COUT=%d, upsample=%d) combination", CIN, COUT, in_up);
+  return ALIBY_ERR_UNSUPPORTED;
+}
+
+extern "C" int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN,
+                                          void* wpk, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ARG_CHECK(ctx && w_oihw && wpk, "pack_conv3x3: null argument");
+  ARG_CHECK(COUT > 0 && COUT % 32 == 0 && CIN % 16 == 0 && CIN_src > 0 && CIN_src <= CIN, "pack_conv3x3: COUT must be a multiple of 32 and CIN of 16");
+  const size_t total = (size_t)COUT * CIN * 9;
+  hipLaunchKernelGGL(k_pack_conv3x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, COUT,
+                     CIN_src, CIN, static_cast<unsigned short*>(wpk), total);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}

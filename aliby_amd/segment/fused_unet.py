@@ -2,11 +2,13 @@
 Fused inference executor for the residual U-Net (aliby_amd/segment/unet.py).
 
 Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
-  * convolutions: torch.nn.functional.conv2d on bf16 channels_last tensors (MIOpen / CK implicit GEMM
-    on the MFMA units) — the only torch compute, as the north star prescribes;
-  * every pointwise stage between two convolutions (BatchNorm affine, ReLU, residual add, style add,
-    nearest 2x upsampling) is ONE pass of the hand-written `k_fused_act` kernel
-    (aliby_amd/csrc/nn_fused.hip) instead of 2-4 eager passes;
+  * the two high-resolution levels (32 / 64 channels, 75 % of the activation bytes) run on the hand-written
+    MFMA convolution unit `k_conv3x3` (aliby_amd/csrc/nn_conv.hip): BatchNorm + ReLU + style shift in the
+    prologue, bias + residual / skip add in the epilogue, so a conv unit is ONE pass over HBM;
+  * the deep levels (128 / 256 channels, compute-bound) keep torch.nn.functional.conv2d on bf16
+    channels_last tensors (MIOpen / CK implicit GEMM), and there every pointwise stage between two
+    convolutions (BatchNorm affine, ReLU, residual add, style add, nearest 2x upsampling) is ONE pass of
+    the hand-written `k_fused_act` kernel (aliby_amd/csrc/nn_fused.hip) instead of 2-4 eager passes;
   * BatchNorm in front of the 1x1 projections is folded into their weights; projections of the up path
     run at the low resolution and are read through the upsample (a 1x1 conv commutes with nearest
     upsampling).
@@ -41,6 +43,8 @@ class _Unit:
             self.scale = F.pad(self.scale, (0, pad_in - self.scale.shape[0]), value=1.0)
             self.shift = F.pad(self.shift, (0, pad_in - self.shift.shape[0]))
         self.w = w.to(dtype).contiguous(memory_format=CL)
+        self.w32 = w.contiguous()  # fp32 OIHW, packed for the MFMA unit on demand
+        self.wpk = None
         self.bias = conv.bias.detach().float().contiguous()  # folded into the next fused pointwise pass
         self.pad = conv.padding
 
@@ -60,10 +64,17 @@ class _Proj:
         self.bias = b.contiguous()
 
 
+# (CIN, COUT, input read through the 2x upsample) instantiations of k_conv3x3
+_MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True)}
+
+
 class FusedUNet:
-    def __init__(self, net, eng, dtype=torch.bfloat16):
-        assert dtype == torch.bfloat16, "the fused pointwise kernel is bf16"
+    def __init__(self, net, eng, dtype=torch.bfloat16, mfma_levels=(0, 1)):
+        assert dtype == torch.bfloat16, "the fused kernels are bf16"
         self.eng, self.dtype = eng, dtype
+        self.mfma_levels = tuple(mfma_levels)
+        self.conv_bytes = 0  # algorithmic bytes / flops of the MFMA conv launches while profiling is on
+        self.conv_flops = 0
         self.lib, self.h = eng.lib, eng.ctx.handle
         net = net.float().eval()
         self.down = []
@@ -71,6 +82,7 @@ class FusedUNet:
             pad = 8 if i == 0 else None
             d = dict(proj=_Proj(blk.proj, dtype, pad), u=[_Unit(blk.conv[0], dtype, pad)] + [_Unit(blk.conv[k], dtype) for k in (1, 2, 3)])
             d["pb1"] = (d["proj"].bias + d["u"][1].bias).contiguous()
+            d["shift1_b0"] = (d["u"][1].scale * d["u"][0].bias + d["u"][1].shift).contiguous()
             self.down.append(d)
         self.up = []
         for blk in net.up:
@@ -116,6 +128,54 @@ class FusedUNet:
     def _conv(x, unit, pad=1):
         return F.conv2d(x, unit.w, None, padding=pad)  # bias is applied by the next fused pass
 
+    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False):
+        """One launch of the MFMA convolution unit: conv3x3(relu(scale*x + shift)) + bias + res."""
+        n, cin = x.shape[0], x.shape[1]
+        cout = unit.w32.shape[0]
+        H, W = (x.shape[2] * 2, x.shape[3] * 2) if in_up else (x.shape[2], x.shape[3])
+        assert (cin, cout, bool(in_up)) in _MFMA_SHAPES, (cin, cout, in_up)
+        if unit.wpk is None:
+            unit.wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(unit.w32), cout, unit.w32.shape[1], cin, _ptr(unit.wpk),
+                                                           _stream_ptr()))
+        sh = unit.shift if shift is None else shift
+        out = self._new(n, cout, H, W)
+        if self.eng.profile is not None:
+            self.conv_bytes += 2 * (x.numel() + out.numel() + (res.numel() if res is not None else 0))
+            self.conv_flops += 2 * 9 * cin * cout * n * H * W
+        with self.eng.timed("conv3x3_mfma"):
+            _lib.check(self.lib.aliby_nn_conv3x3_bf16(
+                self.h, _ptr(x), _ptr(unit.wpk), _ptr(out), _ptr(unit.scale), _ptr(sh), 1 if sh.ndim == 2 else 0,
+                _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
+                1 if in_up else 0, _stream_ptr()))
+        return out
+
+    def _down_mfma(self, i, d, x_raw, x_act):
+        """Residual down block on the MFMA unit: 4 launches, no pointwise passes."""
+        u = d["u"]
+        p = self._conv(x_raw, d["proj"], pad=0)
+        if i == 0:  # 2 -> 32 channels: K = 18 is too thin for the unit; CK conv, its bias rides in the next shift
+            c0 = self._conv(x_act, u[0])
+            x1 = self._unit(c0, u[1], shift=d["shift1_b0"], bias=d["pb1"], res=p)
+        else:
+            c0 = self._unit(x_raw, u[0], bias=u[0].bias)
+            x1 = self._unit(c0, u[1], bias=d["pb1"], res=p)
+        c2 = self._unit(x1, u[2], bias=u[2].bias)
+        return self._unit(c2, u[3], bias=u[3].bias, res=x1)
+
+    def _up_mfma(self, d, x, skip, style):
+        u = d["u"]
+        p_low = self._conv(x, d["proj"], pad=0)  # 1x1 at the low resolution, read through the upsample as a residual
+        if (x.shape[1], skip.shape[1], True) in _MFMA_SHAPES:
+            c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=True)
+        else:  # 128 -> 64: the weights of 32 output channels do not fit one wave's registers
+            _, a0 = self._fused(x, act=u[0], upA=True)
+            c0s, _ = self._fused(self._conv(a0, u[0]), skip, want_sum=True, bias=u[0].bias)
+        sh = [((style @ k.full_w + k.full_b) * k.scale + k.shift).contiguous() for k in u[1:]]  # [N,C] each
+        x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=True)
+        c2 = self._unit(x1, u[2], shift=sh[1], bias=u[2].bias)
+        return self._unit(c2, u[3], shift=sh[2], bias=u[3].bias, res=x1)
+
     # -------------------------------------------------------------------------------- forward
     @torch.no_grad()
     def __call__(self, tiles: torch.Tensor):
@@ -132,6 +192,10 @@ class FusedUNet:
             u = d["u"]
             if i > 0:
                 x_raw = F.max_pool2d(feats[-1], 2, 2)
+            if i in self.mfma_levels:
+                feats.append(self._down_mfma(i, d, x_raw, x_act))
+                continue
+            if i > 0:
                 _, x_act = self._fused(x_raw, act=u[0])
             p = self._conv(x_raw, d["proj"], pad=0)
             c0 = self._conv(x_act, u[0])
@@ -150,6 +214,9 @@ class FusedUNet:
             d = self.up[i]
             u = d["u"]
             skip = feats[i]
+            if i in self.mfma_levels and up:
+                x = self._up_mfma(d, x, skip, style)
+                continue
             p_low = self._conv(x, d["proj"], pad=0)                 # at x's resolution; read through the upsample below
             _, a0 = self._fused(x, act=u[0], upA=up)
             c0 = self._conv(a0, u[0])

@@ -146,6 +146,21 @@ int aliby_average_tiles(aliby_ctx* ctx, const float* ytiles, int F, int Y, int X
 int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* SUM, void* ACT,
                             const float* bias, const float* scale, const float* shift, int N, int H, int W,
                             int C, int upA, int upB, int relu, int shift_per_sample, void* stream);
+/* One convolution unit of the U-Net on the matrix cores (bf16 NHWC, fp32 accumulate), hand-written MFMA
+ * implicit GEMM with the pointwise stages fused around it:
+ *   OUT[n,y,x,:] = conv3x3( relu(scale[c]*IN[n, y>>in_up, x>>in_up, c] + shift[n or 0, c]), zero padded )
+ *                  + bias[:] + RES[n, y>>res_up, x>>res_up, :]
+ * (bias, RES may be NULL).  This is cellpose's `batchconv` / `batchconvstyle` (BatchNorm -> ReLU -> Conv2d)
+ * plus the residual / skip / style adds of `resdown` / `resup`, i.e. the network `model.eval`
+ * (segment/dispatch.py:208-215) runs.  wpk comes from the packing call below.  Supported (CIN, COUT, in_up):
+ * (32,32,0) (32,64,0) (64,64,0) (64,32,1); anything else returns ALIBY_ERR_UNSUPPORTED. */
+int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                          const float* shift, int shift_per_sample, const float* bias, const void* res,
+                          int res_up, int N, int H, int W, int CIN, int COUT, int in_up, void* stream);
+/* float32 OIHW [COUT, CIN_src, 3, 3] device weights -> the MFMA fragment order the kernel above reads
+ * ([COUT/32][9 taps][CIN/16][64 lanes][8] bf16, COUT*CIN*9*2 bytes; input channels >= CIN_src are zero). */
+int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk,
+                               void* stream);
 /* network output bf16 NHWC [N,H,W,Cpad] (+ bias[Cout]) -> float32 NCHW [N,Cout,H,W]. */
 int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W, int Cpad, int Cout,
                               const float* bias, float* out, void* stream);

@@ -1,0 +1,108 @@
+"""
+GPU parity of the hand-written MFMA convolution unit (aliby_amd/csrc/nn_conv.hip) against a plain PyTorch
+fp32 reference of the same op:  conv3x3(relu(scale*x + shift)) + bias + residual.
+
+Two kinds of case: small-integer data, where every product and sum is exact in bf16/fp32, so the comparison
+is bit-exact and any mistake in the MFMA fragment / channel-permutation / halo logic shows up as a wrong
+integer; and random data, within bf16 output rounding (2^-8 relative to the row's magnitude).
+"""
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True)]
+
+
+def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    n, cin = x.shape[0], x.shape[-1]
+    cout = w.shape[0]
+    wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), cout, w.shape[1], cin, _ptr(wpk), _stream_ptr()))
+    out = torch.full((n, H, W, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
+        engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1 if shift.ndim == 2 else 0,
+        _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
+        1 if in_up else 0, _stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
+def _reference(x, w, scale, shift, bias, res, res_up, in_up):
+    import torch
+    import torch.nn.functional as F
+
+    xf = x.float().permute(0, 3, 1, 2)
+    sh = shift if shift.ndim == 2 else shift[None]
+    a = torch.relu(xf * scale[None, :, None, None] + sh[:, :, None, None]).bfloat16().float()
+    if in_up:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    y = F.conv2d(a, w.bfloat16().float(), None, padding=1)
+    if bias is not None:
+        y = y + bias[None, :, None, None]
+    if res is not None:
+        r = res.float().permute(0, 3, 1, 2)
+        if res_up:
+            r = F.interpolate(r, scale_factor=2, mode="nearest")
+        y = y + r
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,in_up", COMBOS)
+def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up):
+    import torch
+
+    torch.backends.cudnn.allow_tf32 = False
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    n, H, W = 3, 44, 70  # neither a multiple of the tile height nor of the 32-pixel strip
+    ih, iw = (H // 2, W // 2) if in_up else (H, W)
+    x = torch.randint(-1, 3, (n, ih, iw, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
+    scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
+    res = torch.randint(-3, 4, (n, H // 2, W // 2, cout), generator=g).to(torch.bfloat16).cuda()
+    out = _run(engine, x, w, scale, shift, bias, res, True, in_up, H, W)
+    ref = _reference(x, w, scale, shift, bias, res, True, in_up)
+    assert float(ref.abs().max()) <= 256  # exactly representable in bf16
+    assert torch.equal(out.float(), ref)
+
+
+@pytest.mark.parametrize("cin,cout,in_up", COMBOS)
+def test_conv_unit_random_data_full_tile_shapes(engine, cin, cout, in_up):
+    import torch
+
+    g = torch.Generator().manual_seed(7 + cin + cout)
+    n = 5
+    H = W = 224 if cout == 32 else 112
+    ih, iw = (H // 2, W // 2) if in_up else (H, W)
+    x = torch.randn(n, ih, iw, cin, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin**0.5)).cuda()
+    scale = (torch.rand(cin, generator=g) + 0.5).cuda()
+    shift = (torch.randn(cin, generator=g) * 0.2).cuda()  # shared shift (down path)
+    res = torch.randn(n, H, W, cout, generator=g).to(torch.bfloat16).cuda()
+    out = _run(engine, x, w, scale, shift, None, res, False, in_up, H, W).float()
+    ref = _reference(x, w, scale, shift, None, res, False, in_up)
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2.0**-7, float(err)
+    # no bias, no residual
+    out2 = _run(engine, x, w, scale, shift, None, None, False, in_up, H, W).float()
+    ref2 = _reference(x, w, scale, shift, None, None, False, in_up)
+    assert float((out2 - ref2).abs().max() / ref2.abs().max()) < 2.0**-7
+
+
+def test_conv_unit_rejects_unsupported_shapes(engine):
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    x = torch.zeros(1, 8, 8, 16, dtype=torch.bfloat16, device="cuda")
+    f = torch.zeros(16, device="cuda")
+    with pytest.raises(Exception, match="unsupported"):
+        _lib.check(engine.lib.aliby_nn_conv3x3_bf16(engine.ctx.handle, _ptr(x), _ptr(x), _ptr(x), _ptr(f), _ptr(f), 0, 0, 0, 0,
+                                                    1, 8, 8, 16, 16, 0, _stream_ptr()))

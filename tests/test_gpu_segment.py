@@ -199,9 +199,11 @@ def test_fused_unet_matches_module_forward(engine):
     x = torch.randn(6, 2, 224, 224, generator=g).cuda().contiguous()
     with torch.no_grad():
         y_ref, s_ref = net(x)
-    fused = FusedUNet(net, engine)
-    y, s = fused(x)
-    assert y.shape == y_ref.shape == (6, 3, 224, 224) and y.dtype == torch.float32
-    err = (y - y_ref).norm() / y_ref.norm()
-    assert err < 0.03, float(err)
-    assert ((s - s_ref).norm() / s_ref.norm()) < 0.03
+    for levels in ((0, 1), ()):  # MFMA conv unit on levels 0-1 (default) | MIOpen convs + fused pointwise everywhere
+        fused = FusedUNet(net, engine, mfma_levels=levels)
+        y, s = fused(x)
+        assert y.shape == y_ref.shape == (6, 3, 224, 224) and y.dtype == torch.float32
+        err = (y - y_ref).norm() / y_ref.norm()
+        assert err < 0.03, (levels, float(err))
+        assert ((s - s_ref).norm() / s_ref.norm()) < 0.03
+        print("fused unet", levels, "rel l2 err vs fp32 module:", float(err))
