@@ -55,6 +55,7 @@ struct ConvArgs {
   const float* bias;   // [COUT] or NULL
   const uint4* res;    // [N, H>>res_up, W>>res_up, COUT] bf16 or NULL
   int shift_stride, res_up;
+  int cs, coff;        // input pixel stride and first staged octet, in 16-byte units (a channel slice of a wider tensor)
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
 };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     // ---- stage the raw window: BATCH 16-byte loads per thread in flight at once (unconditional, from clamped
     // addresses: no divergent branch around a load), then the prologue (BatchNorm affine + style shift + ReLU,
     // bf16; the convolution's zero padding is applied AFTER the activation) into the LDS planes
-    const uint4* inN = a.in + (size_t)n * IH * IW * NPL;  // uniform base (SGPR pair) + 32-bit lane offsets
+    const uint4* inN = a.in + (size_t)n * IH * IW * a.cs + a.coff;  // uniform base (SGPR pair) + 32-bit lane offsets
     int p0 = pix0;
     asm volatile("" : "+v"(p0));  // recompute the window coordinates per tile instead of keeping 2*ITERS registers
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
         inside |= (unsigned)(pix < RAW && gy >= 0 && gy < a.H && gxi >= 0 && gxi < a.W) << u;
         const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gxi, 0), a.W - 1);
-        v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * NPL + pl)];
+        v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * a.cs + pl)];
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
@@ -255,6 +256,196 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant with the raw window travelling global -> LDS by LDS-DMA (global_load_lds_dwordx4), one tile
+// AHEAD of the MFMA loop that consumes it: no VGPRs hold the prefetch, so it fits beside the resident
+// weights.  Two LDS images per workgroup: R (raw bf16 window, pixel-major = lane-linear, as the DMA
+// writes it) and A (the activated channel-octet planes the MFMA loop reads).  Per tile:
+//     wait DMA(t), barrier | prologue R -> A | barrier | seed accumulators | issue DMA(t+1) | MFMA | store
+template <int CIN, int COUT, bool UP>
+struct DmaCfg {
+  static constexpr int KC = CIN / 16, NPL = CIN / 8, NCB = COUT / 32;
+  static constexpr int R = CIN >= 64 ? 2 : 4;
+  static constexpr int RG = 4 / NCB;
+  static constexpr int TH = RG * R, TW = 32, LH = TH + 2, LW = TW + 2;
+  static constexpr int RAW = LH * LW;
+  static constexpr int PLANE = NPL == 4 ? RAW + (10 - RAW % 8) % 8 : (RAW | 1);
+  static constexpr int A_SLOTS = NPL * PLANE;
+  static constexpr int PIX_PER_IT = 256 / NPL;
+  static constexpr int ITERS = (RAW + PIX_PER_IT - 1) / PIX_PER_IT;
+  // raw window (at the input resolution)
+  static constexpr int RLH = UP ? TH / 2 + 2 : LH, RLW = UP ? TW / 2 + 2 : LW;
+  static constexpr int RUNITS = RLH * RLW * NPL;            // 16-byte units
+  static constexpr int GIT = (RUNITS + 255) / 256;          // DMA instructions per wave and tile
+  static constexpr int R_SLOTS = GIT * 256;
+  static constexpr int LDS_BYTES = (A_SLOTS + R_SLOTS) * 16;
+  static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;
+};
+
+template <int CIN, int COUT, bool UP>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
+  using cfg = DmaCfg<CIN, COUT, UP>;
+  constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
+  constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, RLW = cfg::RLW;
+  constexpr int PIX_PER_IT = cfg::PIX_PER_IT, ITERS = cfg::ITERS, GIT = cfg::GIT;
+  extern __shared__ uint4 lds[];
+  uint4* const ldsA = lds;
+  uint4* const ldsR = lds + cfg::A_SLOTS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = wave % NCB, rg = wave / NCB;
+  const int px = lane & 31, hh = lane >> 5;
+  const int c0 = cb * 32 + hh * 16;
+
+  bf16x8_t wfrag[9 * KC];
+  {
+    const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(a.wpk) + (size_t)cb * 9 * KC * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 9 * KC; ++i) wfrag[i] = wp[i * 64];
+  }
+  const int pl = tid % NPL, pix0 = tid / NPL;
+  float sc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sc[k] = a.scale[pl * 8 + k];
+
+  const int IH = UP ? a.H >> 1 : a.H, IW = UP ? a.W >> 1 : a.W;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  const int t_end = min(a.ntiles, (xcd + 1) * per_xcd);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+  auto issue_dma = [&](int tile) {
+    const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+    const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+    const int ry0 = UP ? (ty * TH >> 1) - 1 : ty * TH - 1, rx0 = UP ? (tx * TW >> 1) - 1 : tx * TW - 1;
+    const uint4* inN = a.in + (size_t)n * IH * IW * a.cs + a.coff;
+    int t0 = tid;
+    asm volatile("" : "+v"(t0));
+#pragma unroll
+    for (int k = 0; k < GIT; ++k) {
+      const int unit = t0 + k * 256;  // lane-linear: unit u lands at ldsR[u]
+      const int rpix = unit / NPL, oct = unit % NPL;
+      const int rly = rpix / RLW, rlx = rpix - rly * RLW;
+      const int iy = min(max(ry0 + rly, 0), IH - 1), ix = min(max(rx0 + rlx, 0), IW - 1);  // clamped: masked later
+      const uint4* g = inN + (unsigned)((iy * IW + ix) * a.cs + oct);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ldsR + k * 256 + wave_u * 64), 16, 0, 0);
+    }
+  };
+
+  int tile = xcd * per_xcd + slot;
+  if (tile < t_end) issue_dma(tile);
+  for (; tile < t_end; tile += nslots) {
+    const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+    const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int gx = x0 + px, rbase = rg * R;
+
+    // ---- everything this tile needs from global memory besides the window: requested before the DMA wait
+    float sh[8];
+    {
+      const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[k] = sp[k];
+    }
+    float4 b4[4] = {};
+    if (a.bias) {
+      const float4* bp = reinterpret_cast<const float4*>(a.bias + c0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+    }
+    uint4 rr[R][2];
+    if (a.res) {
+      const int RH = a.H >> a.res_up, RWd = a.W >> a.res_up;
+      const uint4* resN = a.res + (size_t)n * RH * RWd * (COUT / 8);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int cy = min(y0 + rbase + r, a.H - 1), cx = min(gx, a.W - 1);
+        const unsigned off = (unsigned)(((cy >> a.res_up) * RWd + (cx >> a.res_up)) * (COUT / 8) + (c0 >> 3));
+        rr[r][0] = resN[off];
+        rr[r][1] = resN[off + 1];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
+    __syncthreads();                                   // ... and everyone's; the previous tile's reads of A are over
+    // ---- prologue R -> A
+    {
+      const int ry0 = UP ? (y0 >> 1) - 1 : y0 - 1, rx0 = UP ? (x0 >> 1) - 1 : x0 - 1;
+      int p0 = pix0;
+      asm volatile("" : "+v"(p0));
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int pix = min(p0 + it * PIX_PER_IT, RAW - 1);
+        const int ly = pix / LW, lx = pix - ly * LW;
+        const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
+        const unsigned keep = 0u - (unsigned)(gy >= 0 && gy < a.H && gxi >= 0 && gxi < a.W);
+        const int rpix = UP ? ((gy >> 1) - ry0) * RLW + ((gxi >> 1) - rx0) : pix;
+        const uint4 v = ldsR[rpix * NPL + pl];
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        unsigned r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float f0 = fmaxf(sc[2 * q] * cv_bf2f(w4[q] & 0xffffu) + sh[2 * q], 0.f);
+          const float f1 = fmaxf(sc[2 * q + 1] * cv_bf2f(w4[q] >> 16) + sh[2 * q + 1], 0.f);
+          r4[q] = cv_pack2(f0, f1) & keep;
+        }
+        ldsA[pl * PLANE + pix] = make_uint4(r4[0], r4[1], r4[2], r4[3]);  // the clamped tail rewrites its own value
+      }
+    }
+    __syncthreads();
+    // ---- seed the accumulators with bias + residual
+    f32x16_t acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
+      }
+      if (a.res) {
+        const unsigned rw[8] = {rr[r][0].x, rr[r][0].y, rr[r][0].z, rr[r][0].w, rr[r][1].x, rr[r][1].y, rr[r][1].z, rr[r][1].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
+          acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + nslots < t_end) issue_dma(tile + nslots);  // R is free: everyone passed the barrier after the prologue
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- implicit GEMM (as in k_conv3x3)
+    const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px;
+    constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
+    bf16x8_t ring[DEPTH];
+    auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
+#pragma unroll
+    for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
+    static_for<NF>([&](auto fc) {
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
+      constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
+      static_for<3>([&](auto dc) {
+        constexpr int dy = decltype(dc)::value, r = ir - dy;
+        if constexpr (r >= 0 && r < R)
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (gx < a.W) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int gy = y0 + rbase + r;
+        if (gy >= a.H) continue;
+        uint4* op = a.out + (size_t)n * a.H * a.W * (COUT / 8) + (unsigned)((gy * a.W + gx) * (COUT / 8) + (c0 >> 3));
+        op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
+                           cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
+        op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
+                           cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
+      }
+    }
+  }
+}
+
 // Packed layout: [cout block cb][tap][k-step kc][lane][8 bf16]; lane l holds the MFMA A fragment
 // A[row m = l&31][k = 8*(l>>5) + j] = W[cb*32 + chan(m)][cin = 16*kc + 8*(l>>5) + j][tap], with
 // chan(m) = 16*((m>>2)&1) + (m&3) + 4*(m>>3) (see the header comment).
@@ -276,7 +467,32 @@ __global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, u
 }
 
 template <int CIN, int COUT, bool UP>
+int launch_conv_dma(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
+  using cfg = DmaCfg<CIN, COUT, UP>;
+  a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
+  a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
+  const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
+  ARG_CHECK(nt < INT_MAX, "conv3x3: too many tiles");
+  a.ntiles = (int)nt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<CIN, COUT, UP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
+    attr_done = true;
+  }
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int nslots = per_xcd < 64 ? per_xcd : 64;  // 2 workgroups per CU, 32 CUs per XCD
+  hipLaunchKernelGGL((k_conv3x3_dma<CIN, COUT, UP>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+template <int CIN, int COUT, bool UP>
 int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
+  // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
+  // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
+  static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
+  if (use_dma) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);
   using cfg = ConvCfg<CIN, COUT>;
   a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
   a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
@@ -301,7 +517,7 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
 extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                                      const float* shift, int shift_per_sample, const float* bias, const void* res,
                                      int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
-                                     void* stream_) {
+                                     int in_channels, int in_channel0, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3: null argument");
   ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3: empty shape");
@@ -315,12 +531,18 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   a.shift = shift;
   a.bias = bias;
   a.res = static_cast<const uint4*>(res);
-  a.shift_stride = shift_per_sample ? CIN : 0;
+  a.shift_stride = shift_per_sample == 1 ? CIN : shift_per_sample;  // 1 = contiguous [N, CIN]; >1 = row stride in floats
   a.res_up = res_up ? 1 : 0;
+  if (in_channels <= 0) in_channels = CIN;  // 0 = the input tensor has exactly CIN channels
+  ARG_CHECK(in_channels % 8 == 0 && in_channel0 % 8 == 0 && in_channel0 >= 0 && in_channel0 + CIN <= in_channels,
+            "conv3x3: channel slice must be octet aligned and inside the input tensor");
+  a.cs = in_channels / 8;
+  a.coff = in_channel0 / 8;
   a.N = N; a.H = H; a.W = W;
   if (CIN == 32 && COUT == 32 && !in_up) return launch_conv<32, 32, false>(ctx, a, stream);
   if (CIN == 64 && COUT == 32 && in_up) return launch_conv<64, 32, true>(ctx, a, stream);
   if (CIN == 64 && COUT == 64 && !in_up) return launch_conv<64, 64, false>(ctx, a, stream);
+  if (CIN == 64 && COUT == 64 && in_up) return launch_conv<64, 64, true>(ctx, a, stream);
   if (CIN == 32 && COUT == 64 && !in_up) return launch_conv<32, 64, false>(ctx, a, stream);
   aliby_set_error("conv3x3: unsupported (CIN=%d, COUT=%d, upsample=%d) combination", CIN, COUT, in_up);
   return ALIBY_ERR_UNSUPPORTED;

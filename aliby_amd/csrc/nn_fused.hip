@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_fused_act(FusedArgs a) {
   const bf16x8* B = a.B ? reinterpret_cast<const bf16x8*>(a.B) + brow : nullptr;
   bf16x8* S = a.SUM ? reinterpret_cast<bf16x8*>(a.SUM) + orow : nullptr;
   bf16x8* T = a.ACT ? reinterpret_cast<bf16x8*>(a.ACT) + orow : nullptr;
-  const float* sh = a.shift ? a.shift + (a.shift_per_sample ? (size_t)n * a.C : 0) : nullptr;
+  const float* sh = a.shift ? a.shift + (size_t)n * a.shift_per_sample : nullptr;  // 0 = shared, else row stride
   for (int i = threadIdx.x; i < rowv; i += blockDim.x) {
     int w, c8;
     if (a.c8_shift >= 0) { w = i >> a.c8_shift; c8 = i & (C8 - 1); }
@@ -143,7 +143,8 @@ int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* 
   FusedArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.SUM = (bf16_t*)SUM; a.ACT = (bf16_t*)ACT;
   a.bias = bias; a.scale = scale; a.shift = shift; a.N = N; a.H = H; a.W = W; a.C = C; a.upA = upA; a.upB = upB;
-  a.relu = relu; a.shift_per_sample = shift_per_sample;
+  a.relu = relu;
+  a.shift_per_sample = shift_per_sample == 1 ? C : shift_per_sample;  // 1 = contiguous [N, C]; >1 = row stride in floats
   const int C8 = C / 8;
   a.c8_shift = -1;
   for (int k = 0; k < 16; ++k) if ((1 << k) == C8) a.c8_shift = k;

@@ -65,7 +65,7 @@ class _Proj:
 
 
 # (CIN, COUT, input read through the 2x upsample) instantiations of k_conv3x3
-_MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True)}
+_MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True)}
 
 
 class FusedUNet:
@@ -94,6 +94,16 @@ class FusedUNet:
                 d["u"].append(u)
             d["pb1"] = (d["proj"].bias + d["u"][1].bias).contiguous()
             self.up.append(d)
+        # all style projections of the up path as ONE GEMM: shift[n, :] = style[n] @ (full_w * scale) + (full_b * scale + shift)
+        ws, bs, off = [], [], 0
+        for d in self.up:
+            for k in d["u"][1:]:
+                ws.append(k.full_w * k.scale[None, :])
+                bs.append(k.full_b * k.scale + k.shift)
+                k.style_slice = (off, off + k.scale.numel())
+                off += k.scale.numel()
+        self.style_w = torch.cat(ws, dim=1).contiguous()  # [style, sum C]
+        self.style_b = torch.cat(bs).contiguous()
         self.out = _Unit(net.output, dtype)
         self.cin = net.nbase[0]
         self.bytes_moved = 0  # bytes read+written by the fused pointwise launches while profiling is on
@@ -113,7 +123,7 @@ class FusedUNet:
         sh = None
         if act is not None:
             sh = shift if shift is not None else act.shift
-            per_sample = 1 if sh.ndim == 2 else 0
+            per_sample = self._sps(sh)
         if self.eng.profile is not None:
             self.bytes_moved += 2 * (A.numel() + (B.numel() if B is not None else 0) + (n * c * H * W) * ((S is not None) + (T is not None)))
         with self.eng.timed("fused_pointwise"):
@@ -128,27 +138,43 @@ class FusedUNet:
     def _conv(x, unit, pad=1):
         return F.conv2d(x, unit.w, None, padding=pad)  # bias is applied by the next fused pass
 
-    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False):
-        """One launch of the MFMA convolution unit: conv3x3(relu(scale*x + shift)) + bias + res."""
-        n, cin = x.shape[0], x.shape[1]
-        cout = unit.w32.shape[0]
+    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False, cin_slice=None):
+        """One launch of the MFMA convolution unit: conv3x3(relu(scale*x + shift)) + bias + res, optionally over the
+        input-channel slice [lo, hi) only (K-split of a convolution wider than one launch holds)."""
+        n, ctot = x.shape[0], x.shape[1]
+        lo, hi = cin_slice if cin_slice is not None else (0, ctot)
+        cin, cout = hi - lo, unit.w32.shape[0]
         H, W = (x.shape[2] * 2, x.shape[3] * 2) if in_up else (x.shape[2], x.shape[3])
         assert (cin, cout, bool(in_up)) in _MFMA_SHAPES, (cin, cout, in_up)
         if unit.wpk is None:
-            unit.wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
-            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(unit.w32), cout, unit.w32.shape[1], cin, _ptr(unit.wpk),
-                                                           _stream_ptr()))
+            unit.wpk = {}
+        if (lo, hi) not in unit.wpk:
+            w = unit.w32[:, lo:hi].contiguous()
+            pk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(w), cout, w.shape[1], cin, _ptr(pk), _stream_ptr()))
+            unit.wpk[(lo, hi)] = pk
         sh = unit.shift if shift is None else shift
+        sh = sh[..., lo:hi]
+        scale = unit.scale[lo:hi]
         out = self._new(n, cout, H, W)
         if self.eng.profile is not None:
-            self.conv_bytes += 2 * (x.numel() + out.numel() + (res.numel() if res is not None else 0))
+            self.conv_bytes += 2 * (x.numel() * cin // ctot + out.numel() + (res.numel() if res is not None else 0))
             self.conv_flops += 2 * 9 * cin * cout * n * H * W
         with self.eng.timed("conv3x3_mfma"):
             _lib.check(self.lib.aliby_nn_conv3x3_bf16(
-                self.h, _ptr(x), _ptr(unit.wpk), _ptr(out), _ptr(unit.scale), _ptr(sh), 1 if sh.ndim == 2 else 0,
+                self.h, _ptr(x), _ptr(unit.wpk[(lo, hi)]), _ptr(out), _ptr(scale), _ptr(sh), self._sps(sh),
                 _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
-                1 if in_up else 0, _stream_ptr()))
+                1 if in_up else 0, ctot, lo, _stream_ptr()))
         return out
+
+    def _style_shift(self, unit):
+        lo, hi = unit.style_slice
+        return self._style_all[:, lo:hi]
+
+    @staticmethod
+    def _sps(sh):
+        """shift_per_sample argument of the kernels: 0 shared, else the row stride in floats."""
+        return 0 if sh.ndim == 1 else sh.stride(0)
 
     def _down_mfma(self, i, d, x_raw, x_act):
         """Residual down block on the MFMA unit: 4 launches, no pointwise passes."""
@@ -168,10 +194,10 @@ class FusedUNet:
         p_low = self._conv(x, d["proj"], pad=0)  # 1x1 at the low resolution, read through the upsample as a residual
         if (x.shape[1], skip.shape[1], True) in _MFMA_SHAPES:
             c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=True)
-        else:  # 128 -> 64: the weights of 32 output channels do not fit one wave's registers
-            _, a0 = self._fused(x, act=u[0], upA=True)
-            c0s, _ = self._fused(self._conv(a0, u[0]), skip, want_sum=True, bias=u[0].bias)
-        sh = [((style @ k.full_w + k.full_b) * k.scale + k.shift).contiguous() for k in u[1:]]  # [N,C] each
+        else:  # 128 -> 64: the weights of 32 output channels x 1152 do not fit one wave's registers; split along K
+            part = self._unit(x, u[0], res=skip, in_up=True, cin_slice=(0, 64))
+            c0s = self._unit(x, u[0], bias=u[0].bias, res=part, in_up=True, cin_slice=(64, 128))
+        sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
         x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=True)
         c2 = self._unit(x1, u[2], shift=sh[1], bias=u[2].bias)
         return self._unit(c2, u[3], shift=sh[2], bias=u[3].bias, res=x1)
@@ -209,6 +235,7 @@ class FusedUNet:
             feats.append(x2)
         style = feats[-1].float().mean(dim=(2, 3))
         style = style / torch.sum(style**2, dim=1, keepdim=True) ** 0.5
+        self._style_all = torch.addmm(self.style_b, style, self.style_w)  # [N, sum C]
         x, up = feats[-1], False
         for i in range(len(self.up) - 1, -1, -1):
             d = self.up[i]
@@ -220,12 +247,12 @@ class FusedUNet:
             p_low = self._conv(x, d["proj"], pad=0)                 # at x's resolution; read through the upsample below
             _, a0 = self._fused(x, act=u[0], upA=up)
             c0 = self._conv(a0, u[0])
-            sh = [(style @ k.full_w + k.full_b) * k.scale + k.shift for k in u[1:]]  # [N,C] each
-            _, a1 = self._fused(c0, skip, act=u[1], shift=sh[0].contiguous(), bias=u[0].bias)
+            sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
+            _, a1 = self._fused(c0, skip, act=u[1], shift=sh[0], bias=u[0].bias)
             c1 = self._conv(a1, u[1])
-            x1, a2 = self._fused_up_sum(p_low, c1, up, u[2], sh[1].contiguous(), d["pb1"])
+            x1, a2 = self._fused_up_sum(p_low, c1, up, u[2], sh[1], d["pb1"])
             c2 = self._conv(a2, u[2])
-            _, a3 = self._fused(c2, act=u[3], shift=sh[2].contiguous(), bias=u[2].bias)
+            _, a3 = self._fused(c2, act=u[3], shift=sh[2], bias=u[2].bias)
             c3 = self._conv(a3, u[3])
             x, _ = self._fused(x1, c3, want_sum=True, bias=u[3].bias)
             up = True
@@ -246,6 +273,6 @@ class FusedUNet:
         with self.eng.timed("fused_pointwise"):
           _lib.check(self.lib.aliby_nn_fused_act_bf16(
             self.h, _ptr(c1), _ptr(p_low), _ptr(S), _ptr(T), _ptr(bias), _ptr(unit.scale), _ptr(shift), n, H, W, c, 0,
-            1 if up else 0, 1, 1,
+            1 if up else 0, 1, self._sps(shift),
             _stream_ptr()))
         return S, T

@@ -139,7 +139,8 @@ int aliby_average_tiles(aliby_ctx* ctx, const float* ytiles, int F, int Y, int X
                         void* stream);
 
 /* Fused pointwise stage between two convolutions of the U-Net (bf16, NHWC): sum = A (+ B) (+ bias[c]), A/B
- * optionally read through a 2x nearest upsample; act = relu?(scale[c]*sum + shift[n,c] or shift[c]).  SUM
+ * optionally read through a 2x nearest upsample; act = relu?(scale[c]*sum + shift[n,c] or shift[c]).
+ * shift_per_sample: 0 = one shift row for all samples, 1 = contiguous [N, C], >1 = row stride in floats.  SUM
  * and/or ACT are written.  Replaces the eager conv-bias / BatchNorm / ReLU / add / style-add / upsample
  * passes of the network that `model.eval` (segment/dispatch.py:208-215) runs; the convolutions themselves
  * stay in PyTorch-ROCm. */
@@ -150,13 +151,17 @@ int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* 
  * implicit GEMM with the pointwise stages fused around it:
  *   OUT[n,y,x,:] = conv3x3( relu(scale[c]*IN[n, y>>in_up, x>>in_up, c] + shift[n or 0, c]), zero padded )
  *                  + bias[:] + RES[n, y>>res_up, x>>res_up, :]
- * (bias, RES may be NULL).  This is cellpose's `batchconv` / `batchconvstyle` (BatchNorm -> ReLU -> Conv2d)
+ * (bias, RES may be NULL; shift_per_sample as for the fused pointwise stage).  This is cellpose's `batchconv` / `batchconvstyle` (BatchNorm -> ReLU -> Conv2d)
  * plus the residual / skip / style adds of `resdown` / `resup`, i.e. the network `model.eval`
- * (segment/dispatch.py:208-215) runs.  wpk comes from the packing call below.  Supported (CIN, COUT, in_up):
- * (32,32,0) (32,64,0) (64,64,0) (64,32,1); anything else returns ALIBY_ERR_UNSUPPORTED. */
+ * (segment/dispatch.py:208-215) runs.  wpk comes from the packing call below.  IN may be a channel slice
+ * [in_channel0, in_channel0 + CIN) of a tensor with in_channels channels (0 = exactly CIN): a convolution
+ * over more input channels than one launch holds is split along K, each launch adding to the previous one
+ * through RES.  Supported (CIN, COUT, in_up): (32,32,0) (32,64,0) (64,64,0) (64,32,1) (64,64,1); anything
+ * else returns ALIBY_ERR_UNSUPPORTED. */
 int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                           const float* shift, int shift_per_sample, const float* bias, const void* res,
-                          int res_up, int N, int H, int W, int CIN, int COUT, int in_up, void* stream);
+                          int res_up, int N, int H, int W, int CIN, int COUT, int in_up, int in_channels,
+                          int in_channel0, void* stream);
 /* float32 OIHW [COUT, CIN_src, 3, 3] device weights -> the MFMA fragment order the kernel above reads
  * ([COUT/32][9 taps][CIN/16][64 lanes][8] bf16, COUT*CIN*9*2 bytes; input channels >= CIN_src are zero). */
 int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk,

@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True)]
+COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True)]
 
 
 def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
@@ -27,7 +27,7 @@ def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
     _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
         engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1 if shift.ndim == 2 else 0,
         _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
-        1 if in_up else 0, _stream_ptr()))
+        1 if in_up else 0, 0, 0, _stream_ptr()))
     torch.cuda.synchronize()
     return out
 
@@ -96,6 +96,38 @@ def test_conv_unit_random_data_full_tile_shapes(engine, cin, cout, in_up):
     assert float((out2 - ref2).abs().max() / ref2.abs().max()) < 2.0**-7
 
 
+def test_conv_unit_k_split_over_channel_slices(engine):
+    """128 -> 64 through the upsample as two launches over input-channel halves, the second adding to the first."""
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    g = torch.Generator().manual_seed(11)
+    n, H, W, ctot, cout = 3, 56, 72, 128, 64
+    x = torch.randint(-1, 3, (n, H // 2, W // 2, ctot), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, ctot, 3, 3), generator=g) * (torch.rand(cout, ctot, 3, 3, generator=g) < 0.1)).float().cuda()
+    scale = torch.randint(1, 3, (ctot,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (ctot,), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
+    skip = torch.randint(-3, 4, (n, H, W, cout), generator=g).to(torch.bfloat16).cuda()
+    outs = []
+    res = skip
+    for lo, b in ((0, None), (64, bias)):
+        wk = w[:, lo:lo + 64].contiguous()
+        wpk = torch.empty(cout * 64 * 9, dtype=torch.bfloat16, device="cuda")
+        _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(wk), cout, 64, 64, _ptr(wpk), _stream_ptr()))
+        out = torch.empty((n, H, W, cout), dtype=torch.bfloat16, device="cuda")
+        _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
+            engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale[lo:lo + 64]), _ptr(shift[lo:lo + 64]), 0,
+            _ptr(b) if b is not None else 0, _ptr(res), 0, n, H, W, 64, cout, 1, ctot, lo, _stream_ptr()))
+        res = out
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = _reference(x, w, scale, shift, bias, skip, False, True)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(outs[-1].float(), ref)
+
+
 def test_conv_unit_rejects_unsupported_shapes(engine):
     import torch
     from aliby_amd import _lib
@@ -105,4 +137,4 @@ def test_conv_unit_rejects_unsupported_shapes(engine):
     f = torch.zeros(16, device="cuda")
     with pytest.raises(Exception, match="unsupported"):
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(engine.ctx.handle, _ptr(x), _ptr(x), _ptr(x), _ptr(f), _ptr(f), 0, 0, 0, 0,
-                                                    1, 8, 8, 16, 16, 0, _stream_ptr()))
+                                                    1, 8, 8, 16, 16, 0, 0, 0, _stream_ptr()))
