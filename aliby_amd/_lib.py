@@ -72,6 +72,7 @@ _SIGNATURES = {
     "aliby_nn_fused_act_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "aliby_nn_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "aliby_nn_pack_conv3x3_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_nn_out_head_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "aliby_nn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "aliby_nn_tiles_to_nhwc8_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "aliby_masks_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -162,11 +162,11 @@ class CellposeModel:
         with self.eng.timed("unet_forward"), torch.no_grad():
             for i in range(0, ntiles, self.batch_size):
                 if self.fused is not None and g["by"] % 8 == 0 and g["bx"] % 8 == 0:
-                    yb, _ = self.fused(tiles[i : i + self.batch_size])
+                    self.fused(tiles[i : i + self.batch_size], out=yt[i : i + self.batch_size])  # written in place
                 else:
                     xb = tiles[i : i + self.batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
                     yb, _ = self.net(xb)
-                yt[i : i + self.batch_size] = yb.to(torch.float32)
+                    yt[i : i + self.batch_size] = yb.to(torch.float32)
         dP = torch.empty((F, 2, Y, X), dtype=torch.float32, device=self.device)
         prob = torch.empty((F, Y, X), dtype=torch.float32, device=self.device)
         with self.eng.timed("average_tiles"):

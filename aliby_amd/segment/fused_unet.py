@@ -105,6 +105,7 @@ class FusedUNet:
         self.style_w = torch.cat(ws, dim=1).contiguous()  # [style, sum C]
         self.style_b = torch.cat(bs).contiguous()
         self.out = _Unit(net.output, dtype)
+        self.out_w = self.out.w32[:, :, 0, 0].to(dtype).float().contiguous()  # [O, 32], bf16-rounded like the conv it replaces
         self.cin = net.nbase[0]
         self.bytes_moved = 0  # bytes read+written by the fused pointwise launches while profiling is on
 
@@ -204,8 +205,9 @@ class FusedUNet:
 
     # -------------------------------------------------------------------------------- forward
     @torch.no_grad()
-    def __call__(self, tiles: torch.Tensor):
-        """tiles float32 [N, cin, H, W] (contiguous NCHW) -> (y float32 [N,3,H,W], style float32 [N,256])."""
+    def __call__(self, tiles: torch.Tensor, out: torch.Tensor | None = None):
+        """tiles float32 [N, cin, H, W] (contiguous NCHW) -> (y float32 [N,3,H,W], style float32 [N,256]).
+        `out`, when given, is the contiguous float32 [N,3,H,W] buffer y is written into (no copy afterwards)."""
         n, cin, H, W = tiles.shape
         d0 = self.down[0]
         raw = self._new(n, 8, H, W)
@@ -256,11 +258,17 @@ class FusedUNet:
             c3 = self._conv(a3, u[3])
             x, _ = self._fused(x1, c3, want_sum=True, bias=u[3].bias)
             up = True
-        _, a = self._fused(x, act=self.out)
-        yb = self._conv(a, self.out, pad=0)  # [N,3,H,W] channels_last == NHWC with 3 channels
-        y = torch.empty((n, yb.shape[1], H, W), dtype=torch.float32, device="cuda")
-        _lib.check(self.lib.aliby_nn_nhwc_to_nchw_f32(self.h, _ptr(yb), n, H, W, yb.shape[1], yb.shape[1], _ptr(self.out.bias),
-                                                      _ptr(y), _stream_ptr()))
+        y = out if out is not None else torch.empty((n, self.out_w.shape[0], H, W), dtype=torch.float32, device="cuda")
+        assert y.is_contiguous() and y.dtype == torch.float32 and tuple(y.shape) == (n, self.out_w.shape[0], H, W)
+        if x.shape[1] == 32:
+            with self.eng.timed("out_head"):
+                _lib.check(self.lib.aliby_nn_out_head_bf16(self.h, _ptr(x), _ptr(self.out.scale), _ptr(self.out.shift), _ptr(self.out_w),
+                                                           _ptr(self.out.bias), n, H, W, 32, self.out_w.shape[0], _ptr(y), _stream_ptr()))
+        else:
+            _, a = self._fused(x, act=self.out)
+            yb = self._conv(a, self.out, pad=0)  # [N,3,H,W] channels_last == NHWC with 3 channels
+            _lib.check(self.lib.aliby_nn_nhwc_to_nchw_f32(self.h, _ptr(yb), n, H, W, yb.shape[1], yb.shape[1], _ptr(self.out.bias),
+                                                          _ptr(y), _stream_ptr()))
         return y, style
 
     def _fused_up_sum(self, p_low, c1, up, unit, shift, bias):

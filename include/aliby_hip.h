@@ -169,6 +169,12 @@ int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, in
 /* network output bf16 NHWC [N,H,W,Cpad] (+ bias[Cout]) -> float32 NCHW [N,Cout,H,W]. */
 int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W, int Cpad, int Cout,
                               const float* bias, float* out, void* stream);
+/* Output head of the network (cellpose CPnet.output = BatchNorm -> ReLU -> 1x1 Conv2d, the flows + cellprob
+ * that `model.eval` (segment/dispatch.py:208-215) returns): x bf16 NHWC [N,H,W,32] -> float32 NCHW [N,O,H,W],
+ * y = bias[o] + sum_c w[o,c] * bf16(relu(scale[c]*x + shift[c])); w is float32 [O,32] (bf16-representable values
+ * reproduce the bf16 convolution it replaces). */
+int aliby_nn_out_head_bf16(aliby_ctx* ctx, const void* x, const float* scale, const float* shift, const float* w,
+                           const float* bias, int N, int H, int W, int C, int O, float* out, void* stream);
 /* float32 NCHW network tiles (Cin <= 8) -> bf16 NHWC padded to 8 channels: raw copy and relu(bn(x)). */
 int aliby_nn_tiles_to_nhwc8_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W,
                                  const float* scale, const float* shift, void* raw, void* act, void* stream);
