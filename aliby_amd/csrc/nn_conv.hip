@@ -22,6 +22,7 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -37,7 +38,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ float cv_bf2f(unsigned h) { return __uint_as_float(h << 16); }
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned cv_pack2(float lo, float hi) {
   const f32x2_t f = {lo, hi};
@@ -46,10 +46,30 @@ __device__ __forceinline__ unsigned cv_pack2(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned cv_f2bf(float f) { return cv_pack2(f, 0.f) & 0xffffu; }
 
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+// The prologue on one channel octet: bf16 -> relu(scale * x + shift) -> bf16, two channels per instruction
+// (v_pk_fma_f32, v_cvt_pk_bf16_f32; ReLU as v_pk_max_i16 on the bf16 bit patterns: a set sign bit is a negative
+// int16), and zeroed outside the image (`keep` = 0 there: the convolution pads the ACTIVATED tensor).
+__device__ __forceinline__ uint4 conv_act8(uint4 v, const f32x2_t (&sc)[4], const f32x2_t (&sh)[4], unsigned keep) {
+  const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+  unsigned r4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2_t x = {__uint_as_float(w4[q] << 16), __uint_as_float(w4[q] & 0xffff0000u)};
+    const f32x2_t y = __builtin_elementwise_fma(sc[q], x, sh[q]);
+    s16x2_t b = __builtin_bit_cast(s16x2_t, __builtin_convertvector(y, bf16x2_t));
+    const s16x2_t zero = {0, 0};
+    b = __builtin_elementwise_max(b, zero);
+    r4[q] = __builtin_bit_cast(unsigned, b) & keep;
+  }
+  return make_uint4(r4[0], r4[1], r4[2], r4[3]);
+}
+
 struct ConvArgs {
   const uint4* in;     // [N, H>>UP, W>>UP, CIN] bf16
   const uint4* wpk;    // packed weights, see k_pack_conv3x3
   uint4* out;          // [N, H, W, COUT] bf16
+  uint4* pool;         // [N, H/2, W/2, COUT] bf16: 2x2 max pool of OUT, or NULL
   const float* scale;  // [CIN]
   const float* shift;  // [N, CIN] (shift_stride = CIN) or [CIN] (shift_stride = 0)
   const float* bias;   // [COUT] or NULL
@@ -58,7 +78,16 @@ struct ConvArgs {
   int cs, coff;        // input pixel stride and first staged octet, in 16-byte units (a channel slice of a wider tensor)
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
+  unsigned long long* trace;  // diagnostics: per-phase shader-clock stamps of workgroup 0 (NULL in production)
 };
+
+// phase stamps for the latency analysis in DESIGN.md (wave 0 of workgroup 0 only; compiled in, never taken when
+// trace == NULL)
+#define CONV_STAMP(slot_)                                                                   \
+  do {                                                                                      \
+    if (a.trace && blockIdx.x == 0 && tid == 0 && stamp_tile < 16)                          \
+      a.trace[stamp_tile * 8 + (slot_)] = __builtin_amdgcn_s_memtime();                     \
+  } while (0)
 
 template <int CIN, int COUT>
 struct ConvCfg {
@@ -82,9 +111,10 @@ struct ConvCfg {
   // residual rows requested before the prologue (hidden behind it) when the registers allow, else per pass
   static constexpr bool RES_EARLY = CIN < 64;
   static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;  // pixel fragments in flight LDS -> VGPR ahead of their MFMAs
+  static constexpr int DEPTH_POOL = (CIN >= 64 && COUT >= 64) ? 3 : 6;  // the pooling epilogue needs a few registers more
 };
 
-template <int CIN, int COUT, bool UP>
+template <int CIN, int COUT, bool UP, bool POOL>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   using cfg = ConvCfg<CIN, COUT>;
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
@@ -105,9 +135,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   }
   // ---- staging role of this thread: a fixed channel octet
   const int pl = tid % NPL, pix0 = tid / NPL;
-  float sc[8];
+  const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;  // window coordinates of this thread's first pixel
+  f32x2_t sc[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) sc[k] = a.scale[pl * 8 + k];
+  for (int k = 0; k < 4; ++k) sc[k] = f32x2_t{a.scale[pl * 8 + 2 * k], a.scale[pl * 8 + 2 * k + 1]};
 
   const int IH = UP ? a.H >> 1 : a.H, IW = UP ? a.W >> 1 : a.W;
   // XCD-aware persistent schedule: workgroup b lives on XCD b%8; each XCD walks one contiguous eighth of
@@ -116,16 +147,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   const int per_xcd = (a.ntiles + 7) >> 3;
   const int t_end = min(a.ntiles, (xcd + 1) * per_xcd);
 
-  for (int tile = xcd * per_xcd + slot; tile < t_end; tile += nslots) {
+  int stamp_tile = 0;
+  for (int tile = xcd * per_xcd + slot; tile < t_end; tile += nslots, ++stamp_tile) {
+    CONV_STAMP(0);
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    float sh[8];
+    f32x2_t sh[4];
     {
       const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sh[k] = sp[k];
+      for (int k = 0; k < 4; ++k) sh[k] = f32x2_t{sp[2 * k], sp[2 * k + 1]};
     }
     // ---- residual rows and bias seed the accumulators: requested now, unpacked after the prologue
     const int gx = x0 + px;
@@ -146,13 +179,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #pragma unroll
       for (int pass = 0; pass < PASSES; ++pass) load_res(pass);
     }
+    CONV_STAMP(1);
     __syncthreads();  // every wave is done reading the previous tile's planes
+    CONV_STAMP(2);
     // ---- stage the raw window: BATCH 16-byte loads per thread in flight at once (unconditional, from clamped
     // addresses: no divergent branch around a load), then the prologue (BatchNorm affine + style shift + ReLU,
     // bf16; the convolution's zero padding is applied AFTER the activation) into the LDS planes
     const uint4* inN = a.in + (size_t)n * IH * IW * a.cs + a.coff;  // uniform base (SGPR pair) + 32-bit lane offsets
-    int p0 = pix0;
-    asm volatile("" : "+v"(p0));  // recompute the window coordinates per tile instead of keeping 2*ITERS registers
+    int p0 = pix0, qy = ly0, qx = lx0;
+    asm volatile("" : "+v"(p0), "+v"(qy), "+v"(qx));  // recompute the window coordinates per tile: 3 registers, not 2*ITERS
 #pragma unroll
     for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
       uint4 v[BATCH];
@@ -160,31 +195,25 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         if (it0 + u >= ITERS) break;
-        const int pix = p0 + (it0 + u) * PIX_PER_IT;
-        const int ly = pix / LW, lx = pix - ly * LW;
+        // pixel p0 + it*PIX_PER_IT of the window raster, without a division: constant row / column advance + one wrap
+        int lx = qx + ((it0 + u) * PIX_PER_IT) % LW, ly = qy + ((it0 + u) * PIX_PER_IT) / LW;
+        if (lx >= LW) { lx -= LW; ly += 1; }
         const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
-        inside |= (unsigned)(pix < RAW && gy >= 0 && gy < a.H && gxi >= 0 && gxi < a.W) << u;
+        inside |= (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W) << u;
         const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gxi, 0), a.W - 1);
         v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * a.cs + pl)];
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         if (it0 + u >= ITERS) break;
-        const int pix = p0 + (it0 + u) * PIX_PER_IT;
-        const unsigned keep = 0u - ((inside >> u) & 1u);  // all ones inside the image, zero in the padding
-        const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-        unsigned r4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float f0 = fmaxf(sc[2 * q] * cv_bf2f(w4[q] & 0xffffu) + sh[2 * q], 0.f);
-          const float f1 = fmaxf(sc[2 * q + 1] * cv_bf2f(w4[q] >> 16) + sh[2 * q + 1], 0.f);
-          r4[q] = cv_pack2(f0, f1) & keep;
-        }
-        if (it0 + u == ITERS - 1 && pix >= RAW) continue;  // only the last round can run past the window
-        lds[pl * PLANE + pix] = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+        const uint4 o = conv_act8(v[u], sc, sh, 0u - ((inside >> u) & 1u));
+        if (it0 + u == ITERS - 1 && p0 + (it0 + u) * PIX_PER_IT >= RAW) continue;  // only the last round can run past the window
+        lds[pl * PLANE + p0 + (it0 + u) * PIX_PER_IT] = o;
       }
     }
+    CONV_STAMP(3);
     __syncthreads();
+    CONV_STAMP(4);
 
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       // 9*KC*R MFMAs.  The reads run DEPTH fragments ahead of their MFMAs through a register ring; the
       // sched_barrier keeps the compiler from hoisting them further (register budget, see ConvCfg).
       const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px;
-      constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
+      constexpr int NF = (R + 2) * 3 * KC, DEPTH = POOL ? cfg::DEPTH_POOL : cfg::DEPTH;
       bf16x8_t ring[DEPTH];
       auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
 #pragma unroll
@@ -239,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         });
         __builtin_amdgcn_sched_barrier(0);
       });
+      if (pass == PASSES - 1) CONV_STAMP(5);
       // ---- epilogue: bf16, 32 contiguous bytes per lane and row
       if (gx < a.W) {
 #pragma unroll
@@ -252,7 +282,30 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
                              cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
         }
       }
+      // ---- the next level's input, max_pool2d(OUT, 2, 2), straight from the accumulators: row pairs are in this
+      // wave's registers, column pairs are neighbouring lanes (max commutes with the bf16 rounding)
+      if constexpr (POOL) {
+        const int PH = a.H >> 1, PW = a.W >> 1;
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+          const int gy = y0 + rbase + r;
+          const bool writer = (px & 1) == 0 && gx + 1 < a.W && gy + 1 < a.H;
+          uint4* pp = a.pool + (size_t)n * PH * PW * (COUT / 8) + (unsigned)(((gy >> 1) * PW + (gx >> 1)) * (COUT / 8) + (c0 >> 3));
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {  // 8 channels at a time: few live registers beside the resident weights
+            unsigned pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float v0 = fmaxf(acc[r][half * 8 + 2 * q], acc[r + 1][half * 8 + 2 * q]);
+              const float v1 = fmaxf(acc[r][half * 8 + 2 * q + 1], acc[r + 1][half * 8 + 2 * q + 1]);
+              pk[q] = cv_pack2(fmaxf(v0, __shfl_xor(v0, 1)), fmaxf(v1, __shfl_xor(v1, 1)));
+            }
+            if (writer) pp[half] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          }
+        }
+      }
     }
+    CONV_STAMP(6);
   }
 }
 
@@ -304,9 +357,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
     for (int i = 0; i < 9 * KC; ++i) wfrag[i] = wp[i * 64];
   }
   const int pl = tid % NPL, pix0 = tid / NPL;
-  float sc[8];
+  const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;
+  f32x2_t sc[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) sc[k] = a.scale[pl * 8 + k];
+  for (int k = 0; k < 4; ++k) sc[k] = f32x2_t{a.scale[pl * 8 + 2 * k], a.scale[pl * 8 + 2 * k + 1]};
 
   const int IH = UP ? a.H >> 1 : a.H, IW = UP ? a.W >> 1 : a.W;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
@@ -333,20 +387,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
     }
   };
 
-  int tile = xcd * per_xcd + slot;
+  int tile = xcd * per_xcd + slot, stamp_tile = 0;
   if (tile < t_end) issue_dma(tile);
-  for (; tile < t_end; tile += nslots) {
+  for (; tile < t_end; tile += nslots, ++stamp_tile) {
+    CONV_STAMP(0);
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const int gx = x0 + px, rbase = rg * R;
 
     // ---- everything this tile needs from global memory besides the window: requested before the DMA wait
-    float sh[8];
+    f32x2_t sh[4];
     {
       const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sh[k] = sp[k];
+      for (int k = 0; k < 4; ++k) sh[k] = f32x2_t{sp[2 * k], sp[2 * k + 1]};
     }
     float4 b4[4] = {};
     if (a.bias) {
@@ -366,32 +421,30 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
         rr[r][1] = resN[off + 1];
       }
     }
+    CONV_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
     __syncthreads();                                   // ... and everyone's; the previous tile's reads of A are over
+    CONV_STAMP(2);
     // ---- prologue R -> A
     {
       const int ry0 = UP ? (y0 >> 1) - 1 : y0 - 1, rx0 = UP ? (x0 >> 1) - 1 : x0 - 1;
-      int p0 = pix0;
-      asm volatile("" : "+v"(p0));
+      int p0 = pix0, qy = ly0, qx = lx0;
+      asm volatile("" : "+v"(p0), "+v"(qy), "+v"(qx));
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const int pix = min(p0 + it * PIX_PER_IT, RAW - 1);
-        const int ly = pix / LW, lx = pix - ly * LW;
+        int lx = qx + (it * PIX_PER_IT) % LW, ly = qy + (it * PIX_PER_IT) / LW;
+        if (lx >= LW) { lx -= LW; ly += 1; }
         const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
-        const unsigned keep = 0u - (unsigned)(gy >= 0 && gy < a.H && gxi >= 0 && gxi < a.W);
-        const int rpix = UP ? ((gy >> 1) - ry0) * RLW + ((gxi >> 1) - rx0) : pix;
-        const uint4 v = ldsR[rpix * NPL + pl];
-        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-        unsigned r4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float f0 = fmaxf(sc[2 * q] * cv_bf2f(w4[q] & 0xffffu) + sh[2 * q], 0.f);
-          const float f1 = fmaxf(sc[2 * q + 1] * cv_bf2f(w4[q] >> 16) + sh[2 * q + 1], 0.f);
-          r4[q] = cv_pack2(f0, f1) & keep;
-        }
-        ldsA[pl * PLANE + pix] = make_uint4(r4[0], r4[1], r4[2], r4[3]);  // the clamped tail rewrites its own value
+        const unsigned keep = 0u - (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W);
+        const int pix = p0 + it * PIX_PER_IT;
+        // (the last round can run past the window: its raw index is clamped, its value never stored)
+        const int rpix = UP ? min(((gy >> 1) - ry0) * RLW + ((gxi >> 1) - rx0), cfg::RLH * RLW - 1) : min(pix, RAW - 1);
+        const uint4 o = conv_act8(ldsR[rpix * NPL + pl], sc, sh, keep);
+        if (it == ITERS - 1 && pix >= RAW) continue;
+        ldsA[pl * PLANE + pix] = o;
       }
     }
+    CONV_STAMP(3);
     __syncthreads();
     // ---- seed the accumulators with bias + residual
     f32x16_t acc[R];
@@ -413,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (tile + nslots < t_end) issue_dma(tile + nslots);  // R is free: everyone passed the barrier after the prologue
     __builtin_amdgcn_sched_barrier(0);
+    CONV_STAMP(4);
     // ---- implicit GEMM (as in k_conv3x3)
     const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px;
     constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
@@ -431,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+    CONV_STAMP(5);
     if (gx < a.W) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -443,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
                            cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
       }
     }
+    CONV_STAMP(6);
   }
 }
 
@@ -465,6 +521,8 @@ __global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, u
   if (ci < cin_src && co < cout) v = w[((size_t)co * cin_src + ci) * 9 + tap];
   out[i] = (unsigned short)cv_f2bf(v);
 }
+
+unsigned long long* g_conv_trace = nullptr;
 
 template <int CIN, int COUT, bool UP>
 int launch_conv_dma(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
@@ -492,7 +550,7 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
   // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
   static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
-  if (use_dma) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);
+  if (use_dma && !a.pool) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
   using cfg = ConvCfg<CIN, COUT>;
   a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
   a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
@@ -501,13 +559,16 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   a.ntiles = (int)nt;
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
     attr_done = true;
   }
   const int per_xcd = (a.ntiles + 7) / 8;
   const int nslots = per_xcd < 64 ? per_xcd : 64;  // 2 workgroups per CU, 32 CUs per XCD
-  hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  if (a.pool) hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   KERNEL_CHECK();
   return ALIBY_OK;
 }
@@ -517,7 +578,7 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
 extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                                      const float* shift, int shift_per_sample, const float* bias, const void* res,
                                      int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
-                                     int in_channels, int in_channel0, void* stream_) {
+                                     int in_channels, int in_channel0, void* pool_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3: null argument");
   ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3: empty shape");
@@ -533,9 +594,12 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   a.res = static_cast<const uint4*>(res);
   a.shift_stride = shift_per_sample == 1 ? CIN : shift_per_sample;  // 1 = contiguous [N, CIN]; >1 = row stride in floats
   a.res_up = res_up ? 1 : 0;
+  a.pool = static_cast<uint4*>(pool_out);
+  ARG_CHECK(!pool_out || ((H & 1) == 0 && (W & 1) == 0), "conv3x3: pooled output needs even H, W");
   if (in_channels <= 0) in_channels = CIN;  // 0 = the input tensor has exactly CIN channels
   ARG_CHECK(in_channels % 8 == 0 && in_channel0 % 8 == 0 && in_channel0 >= 0 && in_channel0 + CIN <= in_channels,
             "conv3x3: channel slice must be octet aligned and inside the input tensor");
+  a.trace = g_conv_trace;
   a.cs = in_channels / 8;
   a.coff = in_channel0 / 8;
   a.N = N; a.H = H; a.W = W;
@@ -546,6 +610,12 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   if (CIN == 32 && COUT == 64 && !in_up) return launch_conv<32, 64, false>(ctx, a, stream);
   aliby_set_error("conv3x3: unsupported (CIN=%d, COUT=%d, upsample=%d) combination", CIN, COUT, in_up);
   return ALIBY_ERR_UNSUPPORTED;
+}
+
+extern "C" int aliby_debug_conv_trace(aliby_ctx* ctx, void* stamps_dev) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  g_conv_trace = static_cast<unsigned long long*>(stamps_dev);
+  return ALIBY_OK;
 }
 
 extern "C" int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN,

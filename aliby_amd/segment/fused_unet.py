@@ -139,7 +139,7 @@ class FusedUNet:
     def _conv(x, unit, pad=1):
         return F.conv2d(x, unit.w, None, padding=pad)  # bias is applied by the next fused pass
 
-    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False, cin_slice=None):
+    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False, cin_slice=None, pool=False):
         """One launch of the MFMA convolution unit: conv3x3(relu(scale*x + shift)) + bias + res, optionally over the
         input-channel slice [lo, hi) only (K-split of a convolution wider than one launch holds)."""
         n, ctot = x.shape[0], x.shape[1]
@@ -158,15 +158,16 @@ class FusedUNet:
         sh = sh[..., lo:hi]
         scale = unit.scale[lo:hi]
         out = self._new(n, cout, H, W)
+        pooled = self._new(n, cout, H // 2, W // 2) if pool else None
         if self.eng.profile is not None:
-            self.conv_bytes += 2 * (x.numel() * cin // ctot + out.numel() + (res.numel() if res is not None else 0))
+            self.conv_bytes += 2 * (x.numel() * cin // ctot + out.numel() + (res.numel() if res is not None else 0) + (pooled.numel() if pool else 0))
             self.conv_flops += 2 * 9 * cin * cout * n * H * W
         with self.eng.timed("conv3x3_mfma"):
             _lib.check(self.lib.aliby_nn_conv3x3_bf16(
                 self.h, _ptr(x), _ptr(unit.wpk[(lo, hi)]), _ptr(out), _ptr(scale), _ptr(sh), self._sps(sh),
                 _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
-                1 if in_up else 0, ctot, lo, _stream_ptr()))
-        return out
+                1 if in_up else 0, ctot, lo, _ptr(pooled) if pool else 0, _stream_ptr()))
+        return (out, pooled) if pool else out
 
     def _style_shift(self, unit):
         lo, hi = unit.style_slice
@@ -188,7 +189,7 @@ class FusedUNet:
             c0 = self._unit(x_raw, u[0], bias=u[0].bias)
             x1 = self._unit(c0, u[1], bias=d["pb1"], res=p)
         c2 = self._unit(x1, u[2], bias=u[2].bias)
-        return self._unit(c2, u[3], bias=u[3].bias, res=x1)
+        return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=i + 1 < len(self.down))  # (x2, maxpool(x2))
 
     def _up_mfma(self, d, x, skip, style):
         u = d["u"]
@@ -214,14 +215,18 @@ class FusedUNet:
         act = self._new(n, 8, H, W)
         _lib.check(self.lib.aliby_nn_tiles_to_nhwc8_bf16(self.h, _ptr(tiles), n, cin, H, W, _ptr(d0["u"][0].scale),
                                                          _ptr(d0["u"][0].shift), _ptr(raw), _ptr(act), _stream_ptr()))
-        feats = []
+        feats, pooled = [], None
         x_raw, x_act = raw, act
         for i, d in enumerate(self.down):
             u = d["u"]
             if i > 0:
-                x_raw = F.max_pool2d(feats[-1], 2, 2)
+                x_raw = pooled if pooled is not None else F.max_pool2d(feats[-1], 2, 2)
+                pooled = None
             if i in self.mfma_levels:
-                feats.append(self._down_mfma(i, d, x_raw, x_act))
+                x2 = self._down_mfma(i, d, x_raw, x_act)
+                if isinstance(x2, tuple):
+                    x2, pooled = x2  # the block's last convolution also wrote the next level's input
+                feats.append(x2)
                 continue
             if i > 0:
                 _, x_act = self._fused(x_raw, act=u[0])

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True)]
 
 
-def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
+def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W, pool=None):
     import torch
     from aliby_amd import _lib
     from aliby_amd.extraction.engine import _ptr, _stream_ptr
@@ -27,7 +27,7 @@ def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
     _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
         engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1 if shift.ndim == 2 else 0,
         _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
-        1 if in_up else 0, 0, 0, _stream_ptr()))
+        1 if in_up else 0, 0, 0, _ptr(pool) if pool is not None else 0, _stream_ptr()))
     torch.cuda.synchronize()
     return out
 
@@ -66,10 +66,14 @@ def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up):
     shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
     bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
     res = torch.randint(-3, 4, (n, H // 2, W // 2, cout), generator=g).to(torch.bfloat16).cuda()
-    out = _run(engine, x, w, scale, shift, bias, res, True, in_up, H, W)
+    pool = torch.full((n, H // 2, W // 2, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out = _run(engine, x, w, scale, shift, bias, res, True, in_up, H, W, pool=pool)
     ref = _reference(x, w, scale, shift, bias, res, True, in_up)
     assert float(ref.abs().max()) <= 256  # exactly representable in bf16
     assert torch.equal(out.float(), ref)
+    # fused max_pool2d(OUT, 2, 2): the next level's input
+    ref_pool = torch.nn.functional.max_pool2d(ref.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(pool.float(), ref_pool)
 
 
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
@@ -119,7 +123,7 @@ def test_conv_unit_k_split_over_channel_slices(engine):
         out = torch.empty((n, H, W, cout), dtype=torch.bfloat16, device="cuda")
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
             engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale[lo:lo + 64]), _ptr(shift[lo:lo + 64]), 0,
-            _ptr(b) if b is not None else 0, _ptr(res), 0, n, H, W, 64, cout, 1, ctot, lo, _stream_ptr()))
+            _ptr(b) if b is not None else 0, _ptr(res), 0, n, H, W, 64, cout, 1, ctot, lo, 0, _stream_ptr()))
         res = out
         outs.append(out)
     torch.cuda.synchronize()
@@ -137,4 +141,4 @@ def test_conv_unit_rejects_unsupported_shapes(engine):
     f = torch.zeros(16, device="cuda")
     with pytest.raises(Exception, match="unsupported"):
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(engine.ctx.handle, _ptr(x), _ptr(x), _ptr(x), _ptr(f), _ptr(f), 0, 0, 0, 0,
-                                                    1, 8, 8, 16, 16, 0, 0, 0, _stream_ptr()))
+                                                    1, 8, 8, 16, 16, 0, 0, 0, 0, _stream_ptr()))
