@@ -10,7 +10,10 @@
 //
 // MI355X shape: a 256x256 co-occurrence matrix does not fit LDS in any useful way and is >99% empty for
 // a ~1k-pixel object, so the matrix is kept SPARSE: the (lo,hi) grey-level pair of every pixel pair is
-// a 16-bit key, keys are bitonic-sorted in LDS, equal-key runs are the non-zero cells.  Marginals
+// a 16-bit key, keys are bitonic-sorted in LDS, equal-key runs are the non-zero cells.  Objects with few
+// distinct grey levels K (the common case: ~30 for a nucleus) skip the sort: levels are renumbered 0..K-1
+// through a 256-bit presence mask and the K(K+1)/2 cells of the symmetric matrix are counted directly with
+// integer LDS atomics (16-bit counters, two per word) in the memory the keys would have used.  Marginals
 // (p_x, p_{x+y}, p_{x-y}) are integer LDS histograms, so every statistic is exact-integer counts
 // divided once by the total: no atomics on floats, run-to-run deterministic.
 #include "common.h"
@@ -27,6 +30,7 @@ struct TextureArgs {
   int n_obj;
   int cap_pix;   // >= max bbox area (bytes for the grey crop), multiple of 16
   int cap_keys;  // power of two >= max area
+  int cap_cells; // 16-bit cell counters that fit the key area (0: dense path off, an area could overflow 16 bits)
   unsigned char* gscratch;
   int scale, gray_levels;
   double* out;
@@ -57,6 +61,9 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
   __shared__ double vec[4 * 8];
   __shared__ int red_i[8];
   __shared__ int wsum[4];
+  __shared__ unsigned int bits[8];     // presence of the grey levels 1..255 in the object
+  __shared__ unsigned char rk[256];    // grey level -> rank among the present levels
+  __shared__ unsigned char lev[256];   // rank -> grey level
 
   unsigned char* ws = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * ((size_t)a.cap_pix + (size_t)a.cap_keys * 4)) : lds_raw;
   unsigned char* g = ws;
@@ -88,53 +95,95 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
     }
     const int maxv = block_max_i32(gmax, red_i) + 1;  // side of mahotas' matrix: max grey level + 1
     __syncthreads();
+    // ---- present grey levels -> ranks
+    if (tid < 8) bits[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < npix; i += blockDim.x) {
+      const int q = g[i];
+      if (q > 0) atomicOr(&bits[q >> 5], 1u << (q & 31));
+    }
+    __syncthreads();
+    int K = 0;
+    for (int w8 = 0; w8 < 8; ++w8) K += __popc(bits[w8]);
+    for (int q = tid; q < 256; q += blockDim.x) {
+      if ((bits[q >> 5] >> (q & 31)) & 1u) {
+        int r = __popc(bits[q >> 5] & ((1u << (q & 31)) - 1u));
+        for (int w8 = 0; w8 < (q >> 5); ++w8) r += __popc(bits[w8]);
+        rk[q] = (unsigned char)r;
+        lev[r] = (unsigned char)q;
+      }
+    }
+    __syncthreads();
+    const int minlev = K ? lev[0] : 0, maxlev = K ? lev[K - 1] : 0;
+    const int ncell = K * (K + 1) / 2;
+    const bool dense = !GLOBAL && ncell > 0 && ncell <= a.cap_cells;
+    unsigned int* cells = keys;  // two 16-bit counters per word
 
     for (int d = 0; d < 4; ++d) {
       const int dy = DY[d] * a.scale, dx = DX[d] * a.scale;
       double* fo = out + d * TX_NSTAT;
-      // ---- pair keys (order-preserving compaction is unnecessary: keys get sorted) ----------
-      for (int k = tid; k < 256; k += blockDim.x) { hx[k] = 0; hminus[k] = 0; }
-      for (int k = tid; k < 512; k += blockDim.x) hplus[k] = 0;
-      int base = 0;
-      for (int i0 = 0; i0 < npix; i0 += blockDim.x) {
-        const int i = i0 + tid;
-        bool ok = false;
-        unsigned int key = 0;
-        if (i < npix) {
+      // only the occupied ranges of the marginals are ever touched: [minlev, maxlev], [0, maxlev-minlev], [2 minlev, 2 maxlev]
+      for (int k = tid; k <= maxlev - minlev; k += blockDim.x) { hx[minlev + k] = 0; hminus[k] = 0; }
+      for (int k = 2 * minlev + tid; k <= 2 * maxlev; k += blockDim.x) hplus[k] = 0;
+      int NP;
+      if (dense) {
+        // ---- direct counting of the K(K+1)/2 cells --------------------------------------------------
+        for (int k = tid; k < (ncell + 1) / 2; k += blockDim.x) cells[k] = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int i = tid; i < npix; i += blockDim.x) {
           const int r = i / w, c = i % w, r2 = r + dy, c2 = c + dx;
           if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
             const int va = g[i], vb = g[r2 * w + c2];
             if (va > 0 && vb > 0) {
-              ok = true;
-              key = (unsigned)(min(va, vb) << 8) | (unsigned)max(va, vb);
+              const int ra = rk[va], rb = rk[vb];
+              const int hi = max(ra, rb), idx = hi * (hi + 1) / 2 + min(ra, rb);
+              atomicAdd(&cells[idx >> 1], (idx & 1) ? 65536u : 1u);
+              ++mine;
             }
           }
         }
-        const int pos = block_compact_slot(ok, base, wsum);
-        if (ok) keys[pos] = key;
+        NP = block_sum_i32(mine, red_i);
+        __syncthreads();
+      } else {
+        // ---- pair keys (order-preserving compaction is unnecessary: keys get sorted) ----------
+        int base = 0;
+        for (int i0 = 0; i0 < npix; i0 += blockDim.x) {
+          const int i = i0 + tid;
+          bool ok = false;
+          unsigned int key = 0;
+          if (i < npix) {
+            const int r = i / w, c = i % w, r2 = r + dy, c2 = c + dx;
+            if (r2 >= 0 && r2 < h && c2 >= 0 && c2 < w) {
+              const int va = g[i], vb = g[r2 * w + c2];
+              if (va > 0 && vb > 0) {
+                ok = true;
+                key = (unsigned)(min(va, vb) << 8) | (unsigned)max(va, vb);
+              }
+            }
+          }
+          const int pos = block_compact_slot(ok, base, wsum);
+          if (ok) keys[pos] = key;
+        }
+        __syncthreads();
+        NP = base;  // ordered pixel pairs; T = 2*NP entries in the symmetric matrix
       }
-      __syncthreads();
-      const int NP = base;  // ordered pixel pairs; T = 2*NP entries in the symmetric matrix
       if (NP == 0) {
         // mahotas raises ValueError on an empty matrix; CellProfiler records NaN
         for (int k = tid; k < TX_NSTAT; k += blockDim.x) fo[k] = NAN;
         __syncthreads();
         continue;
       }
-      const int n2 = next_pow2(NP);
-      for (int i = NP + tid; i < n2; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
-      block_bitonic_sort(keys, n2);
       const double Tt = 2.0 * (double)NP;
+      if (!dense) {
+        const int n2 = next_pow2(NP);
+        for (int i = NP + tid; i < n2; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
+        block_bitonic_sort(keys, n2);
+      }
 
-      // ---- runs -> cells: integer marginals + cell sums ------------------------------------------
+      // ---- non-zero cells -> integer marginals + cell sums ------------------------------------------
       double acc[3] = {0, 0, 0};  // sum p^2 (as counts^2), sum i*j*count, sum p*log2(p)
-      for (int i = tid; i < NP; i += blockDim.x) {
-        const unsigned int key = keys[i];
-        if (i > 0 && keys[i - 1] == key) continue;
-        int lo_ = i + 1, hi_ = NP;
-        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
-        const int c = lo_ - i;                       // pairs with this unordered grey-level pair
-        const int lo = (int)(key >> 8), hi = (int)(key & 255u);
+      auto cell1 = [&](int c, int lo, int hi) {  // c pixel pairs with the unordered grey-level pair (lo, hi)
         if (lo == hi) {
           atomicAdd(&hx[lo], 2 * c);
           const double p = 2.0 * c / Tt;
@@ -150,6 +199,29 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
         atomicAdd(&hplus[lo + hi], 2 * c);
         atomicAdd(&hminus[hi - lo], 2 * c);
         acc[1] += 2.0 * (double)c * (double)lo * (double)hi;
+      };
+      auto dense_cell = [&](int idx, int& c, int& lo, int& hi) {  // triangular index -> (count, levels)
+        c = (int)((cells[idx >> 1] >> (16 * (idx & 1))) & 0xffffu);
+        int rh = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+        while (rh * (rh + 1) / 2 > idx) --rh;
+        while ((rh + 1) * (rh + 2) / 2 <= idx) ++rh;
+        lo = lev[idx - rh * (rh + 1) / 2];
+        hi = lev[rh];
+      };
+      if (dense) {
+        for (int idx = tid; idx < ncell; idx += blockDim.x) {
+          int c, lo, hi;
+          dense_cell(idx, c, lo, hi);
+          if (c) cell1(c, lo, hi);
+        }
+      } else {
+        for (int i = tid; i < NP; i += blockDim.x) {
+          const unsigned int key = keys[i];
+          if (i > 0 && keys[i - 1] == key) continue;
+          int lo_ = i + 1, hi_ = NP;
+          while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
+          cell1(lo_ - i, (int)(key >> 8), (int)(key & 255u));
+        }
       }
       block_sum_vec_all<3>(acc, vec);
       __syncthreads();
@@ -161,11 +233,13 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
       double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       // m0 = ux, m1 = sum k^2 px, m2 = HX(sum p log p), m3 = contrast, m4 = IDM, m5 = sum p_minus,
       // m6 = sum p_minus^2 (for the vector variance), m7 = difference entropy (sum p log p)
-      for (int k = tid; k < 256; k += blockDim.x) {
+      for (int k = minlev + tid; k <= maxlev; k += blockDim.x) {  // p_x is zero outside the present levels
         const double pxk = (double)hx[k] / Tt;
         m[0] += (double)k * pxk;
         m[1] += (double)k * (double)k * pxk;
         m[2] += plog2p(pxk);
+      }
+      for (int k = tid; k <= maxlev - minlev; k += blockDim.x) {  // |i - j| never exceeds the level range
         const double pm = (double)hminus[k] / Tt;
         m[3] += (double)k * (double)k * pm;
         m[4] += pm / (1.0 + (double)k * (double)k);
@@ -174,7 +248,7 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
       }
       block_sum_vec_all<8>(m, vec);
       double s[3] = {0, 0, 0};  // sum average, sum k^2 p_plus, sum entropy (sum p log p)
-      for (int k = tid; k < 512; k += blockDim.x) {
+      for (int k = 2 * minlev + tid; k <= 2 * maxlev; k += blockDim.x) {
         const double pp = (double)hplus[k] / Tt;
         s[0] += (double)k * pp;
         s[1] += (double)k * (double)k * pp;
@@ -184,15 +258,23 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
 
       // HXY1 = -sum_ij p_ij log2(px_i py_j): second pass over the cells now that p_x is complete
       double hxy = 0;
-      for (int i = tid; i < NP; i += blockDim.x) {
-        const unsigned int key = keys[i];
-        if (i > 0 && keys[i - 1] == key) continue;
-        int lo_ = i + 1, hi_ = NP;
-        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
-        const int c = lo_ - i;
-        const int lo = (int)(key >> 8), hi = (int)(key & 255u);
-        const double pl = (double)hx[lo] / Tt, ph = (double)hx[hi] / Tt;
-        hxy += (2.0 * (double)c / Tt) * log2(pl * ph);
+      if (dense) {
+        for (int idx = tid; idx < ncell; idx += blockDim.x) {
+          int c, lo, hi;
+          dense_cell(idx, c, lo, hi);
+          if (c) hxy += (2.0 * (double)c / Tt) * log2(((double)hx[lo] / Tt) * ((double)hx[hi] / Tt));
+        }
+      } else {
+        for (int i = tid; i < NP; i += blockDim.x) {
+          const unsigned int key = keys[i];
+          if (i > 0 && keys[i - 1] == key) continue;
+          int lo_ = i + 1, hi_ = NP;
+          while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
+          const int c = lo_ - i;
+          const int lo = (int)(key >> 8), hi = (int)(key & 255u);
+          const double pl = (double)hx[lo] / Tt, ph = (double)hx[hi] / Tt;
+          hxy += (2.0 * (double)c / Tt) * log2(pl * ph);
+        }
       }
       double hv[1] = {hxy};
       block_sum_vec_all<1>(hv, vec);
@@ -243,9 +325,10 @@ extern "C" int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, co
   a.tab = table_dev; a.n_obj = n_obj; a.scale = scale; a.gray_levels = gray_levels;
   a.out = out; a.ld = ld; a.col0 = col0;
   a.cap_pix = (int)(((size_t)max_h * max_w + 15) & ~(size_t)15);
-  int ck = 64;
+  int ck = 2048;  // >= 4096 16-bit cells for the direct-counting path (K <= 90 distinct grey levels)
   while (ck < max_area) ck <<= 1;
   a.cap_keys = ck;
+  a.cap_cells = max_area < 65536 ? 2 * ck : 0;
   const size_t need = (size_t)a.cap_pix + (size_t)ck * 4;
   hipStream_t s = as_stream(stream);
   if (need <= 96 * 1024) {
