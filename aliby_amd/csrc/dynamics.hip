@@ -356,24 +356,49 @@ __global__ __launch_bounds__(256) void k_diffuse(QcArgs a) {
     const int niter = a.niter_tile[o.tile];
     double* src = T0;
     double* dst = T1;
+    // One heat source at the centre, niter sweeps of the 9-point mean.  T is zero outside the mask for the whole
+    // run (only mask pixels are ever written), so the reference's "neighbour * mask" products add exactly the
+    // neighbour's value or +0.0 and are dropped; the order of the nine additions is the reference's.  A lane
+    // walks down one column strip with the 3x3 window rolling through registers: 3 LDS reads per pixel, not 9
+    // (+9 mask bytes).  The "+1 at the centre" of sweep it+1 is applied by the lane that writes the centre in
+    // sweep it, which leaves one barrier per sweep.
+    const int ngrp = max(1, (int)blockDim.x / max(w, 1));      // row groups working side by side
+    const int rows_per = (h + ngrp - 1) / ngrp;
+    const int grp = tid / max(w, 1), col0 = tid - grp * w;
+    __syncthreads();
+    if (tid == 0 && niter > 0) src[cidx] += 1.0;
     for (int it = 0; it < niter; ++it) {
       __syncthreads();
-      if (tid == 0) src[cidx] += 1.0;
-      __syncthreads();
-      for (int i = tid; i < h * w; i += blockDim.x) {
-        const int q = (i / w + 1) * pw + (i % w) + 1;
-        if (!mk[q]) continue;
-        double acc = 0.0;
-        acc = acc + src[q] * 1.0;
-        acc = acc + src[q - pw] * (double)mk[q - pw];
-        acc = acc + src[q + pw] * (double)mk[q + pw];
-        acc = acc + src[q - 1] * (double)mk[q - 1];
-        acc = acc + src[q + 1] * (double)mk[q + 1];
-        acc = acc + src[q - pw - 1] * (double)mk[q - pw - 1];
-        acc = acc + src[q - pw + 1] * (double)mk[q - pw + 1];
-        acc = acc + src[q + pw - 1] * (double)mk[q + pw - 1];
-        acc = acc + src[q + pw + 1] * (double)mk[q + pw + 1];
-        dst[q] = acc / 9.0;
+      const bool more = it + 1 < niter;
+      if (grp < ngrp) {
+        const int r0 = grp * rows_per, r1 = min(h, r0 + rows_per);
+        for (int c = col0; c < w; c += (ngrp == 1 ? (int)blockDim.x : w)) {
+          if (r0 >= r1) break;
+          int q = (r0 + 1) * pw + c + 1;
+          double a0 = src[q - pw - 1], a1 = src[q - pw], a2 = src[q - pw + 1];
+          double b0 = src[q - 1], b1 = src[q], b2 = src[q + 1];
+          for (int r = r0; r < r1; ++r, q += pw) {
+            const double c0 = src[q + pw - 1], c1 = src[q + pw], c2 = src[q + pw + 1];
+            if (mk[q]) {
+              double acc = 0.0;
+              acc = acc + b1;
+              acc = acc + a1;
+              acc = acc + c1;
+              acc = acc + b0;
+              acc = acc + b2;
+              acc = acc + a0;
+              acc = acc + a2;
+              acc = acc + c0;
+              acc = acc + c2;
+              double v = acc / 9.0;
+              if (more && q == cidx) v += 1.0;
+              dst[q] = v;
+            }
+            a0 = b0; a1 = b1; a2 = b2;
+            b0 = c0; b1 = c1; b2 = c2;
+          }
+          if (ngrp > 1) break;  // one column per lane when the box is narrower than the workgroup
+        }
       }
       double* t = src; src = dst; dst = t;
     }
