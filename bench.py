@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic FOVs generated per rank (replicated)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--net-dtype", default="bfloat16", choices=["bfloat16", "float32", "float16"])
+    ap.add_argument("--net-batch", type=int, default=288, help="224x224 tiles per U-Net forward (the reference's batch_size knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -135,7 +136,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = CellposeModel(net_dtype=args.net_dtype, seed=0, flows_override=lambda x: (dP_true, prob_true),
-                              run_network_with_override=True, batch_size=96)
+                              run_network_with_override=True, batch_size=args.net_batch)
     eng = model.eng
     torch.cuda.synchronize()
     n_tiles_net = B * model._geometry(Y, X)["ny"] * model._geometry(Y, X)["nx"]

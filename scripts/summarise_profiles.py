@@ -1,0 +1,70 @@
+"""Turn the rocprofv3 outputs of scripts/profile_bench.sh into the small summaries committed under profiles/."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01c"
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name[:110]
+
+
+# ---- kernel stats over the LAST traced step (steady state: after MIOpen's find phase)
+files = glob.glob(f"gpurun_out/prof_{tag}/**/*kernel_trace.csv", recursive=True)
+if files:
+    rows = sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "k_normalize99" in r["Kernel_Name"]]
+    seg = rows[marks[-2]:marks[-1]] if len(marks) >= 2 else rows
+    agg = collections.OrderedDict()
+    for r in seg:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = agg.setdefault(short(r["Kernel_Name"]), [0, 0, 10**12, 0])
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    with open(f"profiles/{tag}_kernel_stats_steady_step.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, a[0], round(a[1] / 1e3, 1), round(a[1] / a[0] / 1e3, 2), round(a[2] / 1e3, 2), round(a[3] / 1e3, 2), round(100 * a[1] / tot, 2)])
+    print("steady step: kernel time", tot / 1e6, "ms over", len(seg), "launches")
+
+# ---- HBM traffic of the hand-written kernels from the PMC passes
+traffic = {}
+for which, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    files = glob.glob(f"gpurun_out/pmc_{tag}_{which}/**/*counter_collection.csv", recursive=True)
+    if not files:
+        continue
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] != col:
+            continue
+        k = short(r["Kernel_Name"])
+        t = traffic.setdefault(k, {"FETCH_SIZE": [], "WRITE_SIZE": []})
+        t[col].append(float(r["Counter_Value"]))
+groups = {"conv3x3_mfma": "k_conv3x3", "fused_pointwise": "k_fused_act", "out_head": "k_out_head"}
+out = {}
+with open(f"profiles/{tag}_pmc_hbm_traffic_summary.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "FETCH_SIZE_KB_avg (as reported)", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch (2*FETCH + WRITE, gfx950 correction)"])
+    for k, t in sorted(traffic.items()):
+        if not t["FETCH_SIZE"] or not t["WRITE_SIZE"] or not k.startswith("k_"):
+            continue
+        fa = sum(t["FETCH_SIZE"]) / len(t["FETCH_SIZE"]); wa = sum(t["WRITE_SIZE"]) / len(t["WRITE_SIZE"])
+        w.writerow([k, len(t["FETCH_SIZE"]), round(fa, 1), round(wa, 1), round((2 * fa + wa) * 1024)])
+for g, prefix in groups.items():
+    fs = [v for k, t in traffic.items() if k.startswith(prefix) for v in t["FETCH_SIZE"]]
+    ws = [v for k, t in traffic.items() if k.startswith(prefix) for v in t["WRITE_SIZE"]]
+    if fs and ws:
+        out[g] = {"kernel": prefix + "*", "launches": len(fs), "fetch_size_kb_per_launch": sum(fs) / len(fs),
+                  "write_size_kb_per_launch": sum(ws) / len(ws),
+                  "hbm_bytes_per_launch": (2 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024,
+                  "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1`; "
+                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); average over all launches "
+                         "of the group in the run (same launch mix as the timed region: launches are per U-Net batch)",
+                  "source": f"profiles/{tag}_pmc_hbm_traffic_summary.csv"}
+if out:
+    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+    print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out.items()}), "MB per launch")
