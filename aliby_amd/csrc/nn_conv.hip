@@ -76,6 +76,7 @@ struct ConvArgs {
   const uint4* res;    // [N, H>>res_up, W>>res_up, COUT] bf16 or NULL
   int shift_stride, res_up;
   int cs, coff;        // input pixel stride and first staged octet, in 16-byte units (a channel slice of a wider tensor)
+  int ocs, ocoff;      // the same for OUT / RES / POOL (an output-channel slice of a wider tensor)
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
   unsigned long long* trace;  // diagnostics: per-phase shader-clock stamps of workgroup 0 (NULL in production)
@@ -108,8 +109,6 @@ struct ConvCfg {
   static constexpr int PIX_PER_IT = 256 / NPL;
   static constexpr int ITERS = (RAW + PIX_PER_IT - 1) / PIX_PER_IT;  // staging loads per thread and tile
   static constexpr int BATCH = CIN >= 64 ? (ITERS + 1) / 2 : ITERS;  // staging loads in flight per thread
-  // residual rows requested before the prologue (hidden behind it) when the registers allow, else per pass
-  static constexpr bool RES_EARLY = CIN < 64;
   static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;  // pixel fragments in flight LDS -> VGPR ahead of their MFMAs
   static constexpr int DEPTH_POOL = (CIN >= 64 && COUT >= 64) ? 3 : 6;  // the pooling epilogue needs a few registers more
 };
@@ -163,22 +162,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     // ---- residual rows and bias seed the accumulators: requested now, unpacked after the prologue
     const int gx = x0 + px;
     const int c0 = cb * 32 + hh * 16;
-    uint4 rr[PASSES * R][2];
+    // (pass 0 before the prologue, pass p+1 while pass p is on the matrix cores: one pass worth of registers)
+    uint4 rr[R][2];
     auto load_res = [&](int pass) {  // clamped: rows / columns past the image edge are never stored
       const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
-      const uint4* resN = a.res + (size_t)n * RH * RW * (COUT / 8);
+      const uint4* resN = a.res + (size_t)n * RH * RW * a.ocs + a.ocoff;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int cy = min(y0 + (rg * PASSES + pass) * R + r, a.H - 1), cx = min(gx, a.W - 1);
-        const unsigned off = (unsigned)(((cy >> a.res_up) * RW + (cx >> a.res_up)) * (COUT / 8) + (c0 >> 3));
-        rr[pass * R + r][0] = resN[off];
-        rr[pass * R + r][1] = resN[off + 1];
+        const unsigned off = (unsigned)(((cy >> a.res_up) * RW + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
+        rr[r][0] = resN[off];
+        rr[r][1] = resN[off + 1];
       }
     };
-    if (cfg::RES_EARLY && a.res) {
-#pragma unroll
-      for (int pass = 0; pass < PASSES; ++pass) load_res(pass);
-    }
+    if (a.res) load_res(0);
     CONV_STAMP(1);
     __syncthreads();  // every wave is done reading the previous tile's planes
     CONV_STAMP(2);
@@ -219,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rbase = (rg * PASSES + pass) * R;  // first output row of this wave and pass inside the tile
       f32x16_t acc[R];
-      if (!cfg::RES_EARLY && a.res) load_res(pass);
       {
         float4 b4[4] = {};
         if (a.bias) {
@@ -237,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (a.res) {
-          const uint4 r0 = rr[pass * R + r][0], r1 = rr[pass * R + r][1];
+          const uint4 r0 = rr[r][0], r1 = rr[r][1];
           const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -246,6 +242,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (pass + 1 < PASSES && a.res) load_res(pass + 1);
       __builtin_amdgcn_sched_barrier(0);
       // ---- implicit GEMM.  A pixel fragment (input row ir, column offset dx, k-step kc) serves the up to three
       // output rows r = ir - dy it is a tap of, so it is read from LDS once: (R+2)*3*KC ds_read_b128 for
@@ -275,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         for (int r = 0; r < R; ++r) {
           const int gy = y0 + rbase + r;
           if (gy >= a.H) continue;
-          uint4* op = a.out + (size_t)n * a.H * a.W * (COUT / 8) + (unsigned)((gy * a.W + gx) * (COUT / 8) + (c0 >> 3));
+          uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
           op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
                              cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
           op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
@@ -290,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         for (int r = 0; r < R; r += 2) {
           const int gy = y0 + rbase + r;
           const bool writer = (px & 1) == 0 && gx + 1 < a.W && gy + 1 < a.H;
-          uint4* pp = a.pool + (size_t)n * PH * PW * (COUT / 8) + (unsigned)(((gy >> 1) * PW + (gx >> 1)) * (COUT / 8) + (c0 >> 3));
+          uint4* pp = a.pool + (size_t)n * PH * PW * a.ocs + a.ocoff + (unsigned)(((gy >> 1) * PW + (gx >> 1)) * a.ocs + (c0 >> 3));
 #pragma unroll
           for (int half = 0; half < 2; ++half) {  // 8 channels at a time: few live registers beside the resident weights
             unsigned pk[4];
@@ -318,7 +316,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 template <int CIN, int COUT, bool UP>
 struct DmaCfg {
   static constexpr int KC = CIN / 16, NPL = CIN / 8, NCB = COUT / 32;
-  static constexpr int R = CIN >= 64 ? 2 : 4;
+  // CIN = 128: the 288 weight VGPRs of a wave only fit the 512-register budget of ONE wave per SIMD; the DMA
+  // pipeline (next window in flight during the MFMA loop) is what keeps that single wave fed
+  static constexpr int WAVES_PER_SIMD = CIN >= 128 ? 1 : 2;
+  static constexpr int R = CIN >= 128 ? 4 : (CIN >= 64 ? 2 : 4);
   static constexpr int RG = 4 / NCB;
   static constexpr int TH = RG * R, TW = 32, LH = TH + 2, LW = TW + 2;
   static constexpr int RAW = LH * LW;
@@ -336,7 +337,7 @@ struct DmaCfg {
 };
 
 template <int CIN, int COUT, bool UP>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
+__global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void k_conv3x3_dma(ConvArgs a) {
   using cfg = DmaCfg<CIN, COUT, UP>;
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
   constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, RLW = cfg::RLW;
@@ -412,11 +413,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
     uint4 rr[R][2];
     if (a.res) {
       const int RH = a.H >> a.res_up, RWd = a.W >> a.res_up;
-      const uint4* resN = a.res + (size_t)n * RH * RWd * (COUT / 8);
+      const uint4* resN = a.res + (size_t)n * RH * RWd * a.ocs + a.ocoff;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int cy = min(y0 + rbase + r, a.H - 1), cx = min(gx, a.W - 1);
-        const unsigned off = (unsigned)(((cy >> a.res_up) * RWd + (cx >> a.res_up)) * (COUT / 8) + (c0 >> 3));
+        const unsigned off = (unsigned)(((cy >> a.res_up) * RWd + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
         rr[r][0] = resN[off];
         rr[r][1] = resN[off + 1];
       }
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_dma(ConvArgs a) {
       for (int r = 0; r < R; ++r) {
         const int gy = y0 + rbase + r;
         if (gy >= a.H) continue;
-        uint4* op = a.out + (size_t)n * a.H * a.W * (COUT / 8) + (unsigned)((gy * a.W + gx) * (COUT / 8) + (c0 >> 3));
+        uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
         op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
                            cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
         op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
@@ -539,7 +540,8 @@ int launch_conv_dma(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
     attr_done = true;
   }
   const int per_xcd = (a.ntiles + 7) / 8;
-  const int nslots = per_xcd < 64 ? per_xcd : 64;  // 2 workgroups per CU, 32 CUs per XCD
+  const int cap = 32 * cfg::WAVES_PER_SIMD;  // workgroups per XCD: 32 CUs x (1 or 2) resident workgroups
+  const int nslots = per_xcd < cap ? per_xcd : cap;
   hipLaunchKernelGGL((k_conv3x3_dma<CIN, COUT, UP>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   KERNEL_CHECK();
   return ALIBY_OK;
@@ -578,7 +580,8 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
 extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                                      const float* shift, int shift_per_sample, const float* bias, const void* res,
                                      int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
-                                     int in_channels, int in_channel0, void* pool_out, void* stream_) {
+                                     int in_channels, int in_channel0, int out_channels, int out_channel0,
+                                     void* pool_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3: null argument");
   ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3: empty shape");
@@ -599,6 +602,11 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   if (in_channels <= 0) in_channels = CIN;  // 0 = the input tensor has exactly CIN channels
   ARG_CHECK(in_channels % 8 == 0 && in_channel0 % 8 == 0 && in_channel0 >= 0 && in_channel0 + CIN <= in_channels,
             "conv3x3: channel slice must be octet aligned and inside the input tensor");
+  if (out_channels <= 0) out_channels = COUT;  // 0 = the output tensor has exactly COUT channels
+  ARG_CHECK(out_channels % 8 == 0 && out_channel0 % 8 == 0 && out_channel0 >= 0 && out_channel0 + COUT <= out_channels,
+            "conv3x3: output channel slice must be octet aligned and inside the output tensor");
+  a.ocs = out_channels / 8;
+  a.ocoff = out_channel0 / 8;
   a.trace = g_conv_trace;
   a.cs = in_channels / 8;
   a.coff = in_channel0 / 8;
@@ -607,6 +615,7 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   if (CIN == 64 && COUT == 32 && in_up) return launch_conv<64, 32, true>(ctx, a, stream);
   if (CIN == 64 && COUT == 64 && !in_up) return launch_conv<64, 64, false>(ctx, a, stream);
   if (CIN == 64 && COUT == 64 && in_up) return launch_conv<64, 64, true>(ctx, a, stream);
+  if (CIN == 64 && COUT == 128) return in_up ? launch_conv<64, 128, true>(ctx, a, stream) : launch_conv<64, 128, false>(ctx, a, stream);
   if (CIN == 32 && COUT == 64 && !in_up) return launch_conv<32, 64, false>(ctx, a, stream);
   aliby_set_error("conv3x3: unsupported (CIN=%d, COUT=%d, upsample=%d) combination", CIN, COUT, in_up);
   return ALIBY_ERR_UNSUPPORTED;

@@ -65,11 +65,12 @@ class _Proj:
 
 
 # (CIN, COUT, input read through the 2x upsample) instantiations of k_conv3x3
-_MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True)}
+_MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True), (64, 128, False), (64, 128, True)}
+_POOL_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 128, False)}
 
 
 class FusedUNet:
-    def __init__(self, net, eng, dtype=torch.bfloat16, mfma_levels=(0, 1)):
+    def __init__(self, net, eng, dtype=torch.bfloat16, mfma_levels=(0, 1, 2, 3)):
         assert dtype == torch.bfloat16, "the fused kernels are bf16"
         self.eng, self.dtype = eng, dtype
         self.mfma_levels = tuple(mfma_levels)
@@ -139,35 +140,57 @@ class FusedUNet:
     def _conv(x, unit, pad=1):
         return F.conv2d(x, unit.w, None, padding=pad)  # bias is applied by the next fused pass
 
-    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False, cin_slice=None, pool=False):
-        """One launch of the MFMA convolution unit: conv3x3(relu(scale*x + shift)) + bias + res, optionally over the
-        input-channel slice [lo, hi) only (K-split of a convolution wider than one launch holds)."""
-        n, ctot = x.shape[0], x.shape[1]
-        lo, hi = cin_slice if cin_slice is not None else (0, ctot)
-        cin, cout = hi - lo, unit.w32.shape[0]
+    def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False, pool=False):
+        """conv3x3(relu(scale*x + shift)) + bias + res on the MFMA convolution unit.  One launch when the shape is
+        one of the kernel's instantiations; otherwise the convolution is split along K (64 input channels per
+        launch, each launch adding to the previous one through RES, in place) and along N (128 output channels
+        per launch, written into channel slices of the output)."""
+        n, cin, cout = x.shape[0], x.shape[1], unit.w32.shape[0]
         H, W = (x.shape[2] * 2, x.shape[3] * 2) if in_up else (x.shape[2], x.shape[3])
-        assert (cin, cout, bool(in_up)) in _MFMA_SHAPES, (cin, cout, in_up)
-        if unit.wpk is None:
-            unit.wpk = {}
-        if (lo, hi) not in unit.wpk:
-            w = unit.w32[:, lo:hi].contiguous()
-            pk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
-            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(w), cout, w.shape[1], cin, _ptr(pk), _stream_ptr()))
-            unit.wpk[(lo, hi)] = pk
-        sh = unit.shift if shift is None else shift
-        sh = sh[..., lo:hi]
-        scale = unit.scale[lo:hi]
         out = self._new(n, cout, H, W)
         pooled = self._new(n, cout, H // 2, W // 2) if pool else None
+        if (cin, cout, bool(in_up)) in _MFMA_SHAPES:
+            self._launch_unit(x, unit, (0, cin), (0, cout), out, shift, bias, res, res_up, in_up, pooled)
+            return (out, pooled) if pool else out
+        ks = 64 if cin > 64 else cin
+        ns = 128 if cout > 128 else cout
+        assert cin % ks == 0 and cout % ns == 0 and (ks, ns, bool(in_up)) in _MFMA_SHAPES, (cin, cout, in_up)
+        for n0 in range(0, cout, ns):
+            cur, cur_up = res, res_up
+            for k0 in range(0, cin, ks):
+                last = k0 + ks == cin
+                self._launch_unit(x, unit, (k0, k0 + ks), (n0, n0 + ns), out, shift, bias if last else None, cur, cur_up, in_up,
+                                  pooled if last else None)
+                cur, cur_up = out, False
+        return (out, pooled) if pool else out
+
+    def _launch_unit(self, x, unit, kslice, nslice, out, shift, bias, res, res_up, in_up, pooled):
+        n, ctot, cout_tot = x.shape[0], x.shape[1], out.shape[1]
+        (k0, k1), (n0, n1) = kslice, nslice
+        cin, cout = k1 - k0, n1 - n0
+        H, W = out.shape[2], out.shape[3]
+        assert pooled is None or (cin, cout, bool(in_up)) in _POOL_SHAPES
+        if unit.wpk is None:
+            unit.wpk = {}
+        key = (k0, k1, n0, n1)
+        if key not in unit.wpk:
+            w = unit.w32[n0:n1, k0:k1].contiguous()
+            pk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(w), cout, w.shape[1], cin, _ptr(pk), _stream_ptr()))
+            unit.wpk[key] = pk
+        sh = unit.shift if shift is None else shift
+        sh = sh[..., k0:k1]
+        scale = unit.scale[k0:k1]
         if self.eng.profile is not None:
-            self.conv_bytes += 2 * (x.numel() * cin // ctot + out.numel() + (res.numel() if res is not None else 0) + (pooled.numel() if pool else 0))
-            self.conv_flops += 2 * 9 * cin * cout * n * H * W
+            px_out = n * H * W
+            self.conv_bytes += 2 * (x.numel() * cin // ctot + px_out * cout + (res.numel() * cout // cout_tot if res is not None else 0)
+                                    + (px_out // 4 * cout if pooled is not None else 0))
+            self.conv_flops += 2 * 9 * cin * cout * px_out
         with self.eng.timed("conv3x3_mfma"):
             _lib.check(self.lib.aliby_nn_conv3x3_bf16(
-                self.h, _ptr(x), _ptr(unit.wpk[(lo, hi)]), _ptr(out), _ptr(scale), _ptr(sh), self._sps(sh),
-                _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
-                1 if in_up else 0, ctot, lo, _ptr(pooled) if pool else 0, _stream_ptr()))
-        return (out, pooled) if pool else out
+                self.h, _ptr(x), _ptr(unit.wpk[key]), _ptr(out), _ptr(scale), _ptr(sh), self._sps(sh),
+                _ptr(bias[n0:n1]) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
+                1 if in_up else 0, ctot, k0, cout_tot, n0, _ptr(pooled) if pooled is not None else 0, _stream_ptr()))
 
     def _style_shift(self, unit):
         lo, hi = unit.style_slice
@@ -189,18 +212,14 @@ class FusedUNet:
             c0 = self._unit(x_raw, u[0], bias=u[0].bias)
             x1 = self._unit(c0, u[1], bias=d["pb1"], res=p)
         c2 = self._unit(x1, u[2], bias=u[2].bias)
-        return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=i + 1 < len(self.down))  # (x2, maxpool(x2))
+        return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=i + 1 < len(self.down) and u[3].w32.shape[0] <= 128)  # (x2, maxpool(x2))
 
-    def _up_mfma(self, d, x, skip, style):
+    def _up_mfma(self, d, x, skip, style, up=True):
         u = d["u"]
         p_low = self._conv(x, d["proj"], pad=0)  # 1x1 at the low resolution, read through the upsample as a residual
-        if (x.shape[1], skip.shape[1], True) in _MFMA_SHAPES:
-            c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=True)
-        else:  # 128 -> 64: the weights of 32 output channels x 1152 do not fit one wave's registers; split along K
-            part = self._unit(x, u[0], res=skip, in_up=True, cin_slice=(0, 64))
-            c0s = self._unit(x, u[0], bias=u[0].bias, res=part, in_up=True, cin_slice=(64, 128))
+        c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=up)  # wider than one launch holds: split along K / N
         sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
-        x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=True)
+        x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=up)
         c2 = self._unit(x1, u[2], shift=sh[1], bias=u[2].bias)
         return self._unit(c2, u[3], shift=sh[2], bias=u[3].bias, res=x1)
 
@@ -248,8 +267,9 @@ class FusedUNet:
             d = self.up[i]
             u = d["u"]
             skip = feats[i]
-            if i in self.mfma_levels and up:
-                x = self._up_mfma(d, x, skip, style)
+            if i in self.mfma_levels:
+                x = self._up_mfma(d, x, skip, style, up)
+                up = True
                 continue
             p_low = self._conv(x, d["proj"], pad=0)                 # at x's resolution; read through the upsample below
             _, a0 = self._fused(x, act=u[0], upA=up)

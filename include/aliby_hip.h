@@ -156,14 +156,15 @@ int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* 
  * (segment/dispatch.py:208-215) runs.  wpk comes from the packing call below.  IN may be a channel slice
  * [in_channel0, in_channel0 + CIN) of a tensor with in_channels channels (0 = exactly CIN): a convolution
  * over more input channels than one launch holds is split along K, each launch adding to the previous one
- * through RES.  pool_out, when not NULL, also receives max_pool2d(OUT, 2, 2) as bf16 NHWC [N,H/2,W/2,COUT]
+ * through RES.  OUT / RES / pool_out may likewise be the channel slice [out_channel0, out_channel0 + COUT) of
+ * tensors with out_channels channels (0 = exactly COUT): wide outputs are produced slice by slice.  pool_out, when not NULL, also receives max_pool2d(OUT, 2, 2) as bf16 NHWC [N,H/2,W/2,COUT]
  * (cellpose's `downsample` maxpool, fused into the epilogue of the block's last convolution).
- * Supported (CIN, COUT, in_up): (32,32,0) (32,64,0) (64,64,0) (64,32,1) (64,64,1); anything
- * else returns ALIBY_ERR_UNSUPPORTED. */
+ * Supported (CIN, COUT, in_up): (32,32,0) (32,64,0) (64,64,0) (64,32,1) (64,64,1) (64,128,0) (64,128,1);
+ * anything else returns ALIBY_ERR_UNSUPPORTED. */
 int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                           const float* shift, int shift_per_sample, const float* bias, const void* res,
                           int res_up, int N, int H, int W, int CIN, int COUT, int in_up, int in_channels,
-                          int in_channel0, void* pool_out, void* stream);
+                          int in_channel0, int out_channels, int out_channel0, void* pool_out, void* stream);
 /* Diagnostics: when stamps_dev != NULL, wave 0 of workgroup 0 of every following conv3x3 launch (register-staged
  * variant) writes its shader-clock stamps at the phase boundaries of its first 16 tiles into stamps_dev[16][8]
  * (uint64: 0 tile start, 1 loads issued, 2 after barrier, 3 prologue done, 4 after barrier, 5 MFMA done,

@@ -10,7 +10,7 @@ from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr  # noqa
 
 eng = FeatureEngine()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
-for cin, cout, up, H in [(32, 32, 0, 224), (64, 32, 1, 224), (64, 64, 0, 112), (32, 64, 0, 112)]:
+for cin, cout, up, H in [(32, 32, 0, 224), (64, 32, 1, 224), (64, 64, 0, 112), (32, 64, 0, 112), (64, 128, 0, 56), (64, 128, 0, 28)]:
     ih = H // 2 if up else H
     x = torch.randn(N, ih, ih, cin, device="cuda").bfloat16()
     w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
@@ -24,7 +24,7 @@ for cin, cout, up, H in [(32, 32, 0, 224), (64, 32, 1, 224), (64, 64, 0, 112), (
     for with_res in (0, 1):
         def run():
             _lib.check(eng.lib.aliby_nn_conv3x3_bf16(eng.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1,
-                                                     _ptr(bias), _ptr(res) if with_res else 0, 0, N, H, H, cin, cout, up, 0, 0, 0, _stream_ptr()))
+                                                     _ptr(bias), _ptr(res) if with_res else 0, 0, N, H, H, cin, cout, up, 0, 0, 0, 0, 0, _stream_ptr()))
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -22,7 +22,7 @@ for cin, cout, up, H in [(32, 32, 0, 224)]:
         for rep in range(3):
             _lib.check(eng.lib.aliby_debug_conv_trace(eng.ctx.handle, _ptr(stamps) if rep == 2 else 0))
             _lib.check(eng.lib.aliby_nn_conv3x3_bf16(eng.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1,
-                                                     _ptr(bias), _ptr(res) if with_res else 0, 0, N, H, H, cin, cout, up, 0, 0, 0, _stream_ptr()))
+                                                     _ptr(bias), _ptr(res) if with_res else 0, 0, N, H, H, cin, cout, up, 0, 0, 0, 0, 0, _stream_ptr()))
         torch.cuda.synchronize()
         _lib.check(eng.lib.aliby_debug_conv_trace(eng.ctx.handle, 0))
         s = stamps.cpu().numpy()

@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True)]
+COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True), (64, 128, False), (64, 128, True)]
 
 
 def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W, pool=None):
@@ -27,7 +27,7 @@ def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W, pool=None):
     _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
         engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1 if shift.ndim == 2 else 0,
         _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
-        1 if in_up else 0, 0, 0, _ptr(pool) if pool is not None else 0, _stream_ptr()))
+        1 if in_up else 0, 0, 0, 0, 0, _ptr(pool) if pool is not None else 0, _stream_ptr()))
     torch.cuda.synchronize()
     return out
 
@@ -123,13 +123,41 @@ def test_conv_unit_k_split_over_channel_slices(engine):
         out = torch.empty((n, H, W, cout), dtype=torch.bfloat16, device="cuda")
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
             engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale[lo:lo + 64]), _ptr(shift[lo:lo + 64]), 0,
-            _ptr(b) if b is not None else 0, _ptr(res), 0, n, H, W, 64, cout, 1, ctot, lo, 0, _stream_ptr()))
+            _ptr(b) if b is not None else 0, _ptr(res), 0, n, H, W, 64, cout, 1, ctot, lo, 0, 0, 0, _stream_ptr()))
         res = out
         outs.append(out)
     torch.cuda.synchronize()
     ref = _reference(x, w, scale, shift, bias, skip, False, True)
     assert float(ref.abs().max()) <= 256
     assert torch.equal(outs[-1].float(), ref)
+
+
+def test_conv_unit_n_split_into_output_channel_slices(engine):
+    """64 -> 256 as two launches writing the two 128-channel halves of one output tensor (residual sliced alike)."""
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    g = torch.Generator().manual_seed(12)
+    n, H, W, cin, ctot = 2, 28, 28, 64, 256
+    x = torch.randint(-1, 3, (n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (ctot, cin, 3, 3), generator=g) * (torch.rand(ctot, cin, 3, 3, generator=g) < 0.15)).float().cuda()
+    scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (cin,), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (ctot,), generator=g).float().cuda()
+    res = torch.randint(-3, 4, (n, H, W, ctot), generator=g).to(torch.bfloat16).cuda()
+    out = torch.full((n, H, W, ctot), float("nan"), dtype=torch.bfloat16, device="cuda")
+    for n0 in (0, 128):
+        wk = w[n0:n0 + 128].contiguous()
+        wpk = torch.empty(128 * cin * 9, dtype=torch.bfloat16, device="cuda")
+        _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(wk), 128, cin, cin, _ptr(wpk), _stream_ptr()))
+        _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
+            engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 0, _ptr(bias[n0:n0 + 128]), _ptr(res), 0,
+            n, H, W, cin, 128, 0, 0, 0, ctot, n0, 0, _stream_ptr()))
+    torch.cuda.synchronize()
+    ref = _reference(x, w, scale, shift, bias, res, False, False)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(out.float(), ref)
 
 
 def test_conv_unit_rejects_unsupported_shapes(engine):
@@ -141,4 +169,4 @@ def test_conv_unit_rejects_unsupported_shapes(engine):
     f = torch.zeros(16, device="cuda")
     with pytest.raises(Exception, match="unsupported"):
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(engine.ctx.handle, _ptr(x), _ptr(x), _ptr(x), _ptr(f), _ptr(f), 0, 0, 0, 0,
-                                                    1, 8, 8, 16, 16, 0, 0, 0, 0, _stream_ptr()))
+                                                    1, 8, 8, 16, 16, 0, 0, 0, 0, 0, 0, _stream_ptr()))

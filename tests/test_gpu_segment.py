@@ -199,7 +199,7 @@ def test_fused_unet_matches_module_forward(engine):
     x = torch.randn(6, 2, 224, 224, generator=g).cuda().contiguous()
     with torch.no_grad():
         y_ref, s_ref = net(x)
-    for levels in ((0, 1), ()):  # MFMA conv unit on levels 0-1 (default) | MIOpen convs + fused pointwise everywhere
+    for levels in ((0, 1, 2, 3), (0, 1), ()):  # MFMA conv unit on all levels (default) | levels 0-1 | MIOpen convs + fused pointwise
         fused = FusedUNet(net, engine, mfma_levels=levels)
         y, s = fused(x)
         assert y.shape == y_ref.shape == (6, 3, 224, 224) and y.dtype == torch.float32
