@@ -290,7 +290,36 @@ __global__ __launch_bounds__(256) void k_ranks(RankArgs a) {
       if (in) { vals[pos] = px_load<T>(px, idx); pix[pos] = (int)idx; }
     }
     __syncthreads();
-    const int N = base, n2 = next_pow2(N);
+    const int N = base;
+    // ---- uint16 fast path: presence bitmap over [vmin, vmax] + prefix popcount instead of a sort.  S and P are
+    // reused as the bitmap (32 values per word) and its scan; taken when the value span fits them.
+    bool done = false;
+    if (sizeof(T) == 2 && !GLOBAL) {
+      int lo = INT_MAX, hi = 0;
+      for (int j = tid; j < N; j += blockDim.x) { const int v = (int)vals[j]; lo = min(lo, v); hi = max(hi, v); }
+      const int vmin = block_min_i32(lo, part), vmax = block_max_i32(hi, part);
+      const int w0 = vmin >> 5, nw = (vmax >> 5) - w0 + 1;
+      if (nw <= a.cap) {
+        unsigned int* bits = reinterpret_cast<unsigned int*>(S);
+        __syncthreads();
+        for (int i = tid; i < nw; i += blockDim.x) bits[i] = 0u;
+        __syncthreads();
+        for (int j = tid; j < N; j += blockDim.x) { const int v = (int)vals[j]; atomicOr(&bits[(v >> 5) - w0], 1u << (v & 31)); }
+        __syncthreads();
+        for (int i = tid; i < nw; i += blockDim.x) P[i] = __popc(bits[i]);
+        __syncthreads();
+        block_inclusive_scan(P, nw, part);
+        for (int j = tid; j < N; j += blockDim.x) {
+          const int v = (int)vals[j], wi = (v >> 5) - w0;
+          const unsigned int below = bits[wi] & ((1u << (v & 31)) - 1u);
+          rk[pix[j]] = (unsigned int)(P[wi] - __popc(bits[wi]) + __popc(below));
+        }
+        if (tid == 0) a.rmax[(size_t)oi * a.C + a.channel] = P[nw - 1] - 1;
+        done = true;
+      }
+    }
+    if (done) { __syncthreads(); continue; }
+    const int n2 = next_pow2(N);
     for (int i = tid; i < n2; i += blockDim.x) S[i] = (i < N) ? vals[i] : INFINITY;
     block_bitonic_sort(S, n2);
     for (int i = tid; i < N; i += blockDim.x) P[i] = (i > 0 && S[i] != S[i - 1]) ? 1 : 0;
