@@ -7,7 +7,7 @@
 // bsize=224, tile_overlap=0.1, zero padding to a multiple of 16 plus 8 px per side).
 //
 // All three are streaming passes (HBM-bound).  The 1st/99th percentiles are exact order statistics:
-// a 65536-bin histogram of the uint16 plane + a scan, interpolated like numpy.percentile("linear").
+// found by a two-pass radix select over the uint16 plane (below), interpolated like numpy.percentile("linear").
 #include "common.h"
 
 typedef unsigned short u16;

@@ -52,13 +52,14 @@ def _reference(x, w, scale, shift, bias, res, res_up, in_up):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("shape", [(3, 44, 70), (1, 10, 6), (2, 2, 34)])
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
-def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up):
+def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up, shape):
     import torch
 
     torch.backends.cudnn.allow_tf32 = False
     g = torch.Generator().manual_seed(cin * 131 + cout)
-    n, H, W = 3, 44, 70  # neither a multiple of the tile height nor of the 32-pixel strip
+    n, H, W = shape  # neither multiples of the tile height nor of the 32-pixel strip; images smaller than one tile
     ih, iw = (H // 2, W // 2) if in_up else (H, W)
     x = torch.randint(-1, 3, (n, ih, iw, cin), generator=g).to(torch.bfloat16).cuda()
     w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
