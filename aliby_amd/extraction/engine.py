@@ -75,6 +75,38 @@ class ObjectTable:
     max_w: int
 
 
+class _NoTimer:
+    active = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
+class _Timer:
+    __slots__ = ("eng", "name", "a")
+    active = True
+
+    def __init__(self, eng, name):
+        self.eng, self.name = eng, name
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        b = torch.cuda.Event(enable_timing=True)
+        b.record()
+        self.eng.profile.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
 class FeatureEngine:
     def __init__(self, device: int | None = None):
         if not torch.cuda.is_available():
@@ -85,6 +117,8 @@ class FeatureEngine:
         self.ctx = _lib.default_context(device)
         self.lib = self.ctx.lib
         self.profile = None  # set to {} to time kernel groups with HIP events on the launch stream
+        self.profile_sample = {}  # group name -> n: bracket only every n-th launch of that group
+        self._sample_count = {}
 
     # ---------------------------------------------------------------- host transfer
     def to_host(self, t: torch.Tensor, copy: bool = True) -> np.ndarray:
@@ -107,31 +141,28 @@ class FeatureEngine:
 
     # ---------------------------------------------------------------- profiling
     def timed(self, name: str):
-        """Context manager: brackets the enclosed launches with events on torch's current stream
-        (the stream every kernel is launched on) when profiling is enabled."""
-        eng = self
-
-        class _T:
-            def __enter__(self_):
-                if eng.profile is not None:
-                    self_.a = torch.cuda.Event(enable_timing=True)
-                    self_.b = torch.cuda.Event(enable_timing=True)
-                    self_.a.record()
-                return self_
-
-            def __exit__(self_, *exc):
-                if eng.profile is not None:
-                    self_.b.record()
-                    eng.profile.setdefault(name, []).append((self_.a, self_.b))
-                return False
-
-        return _T()
+        """Context manager: brackets the enclosed launches with events on torch's current stream (the stream every
+        kernel is launched on) when profiling is enabled.  Groups listed in `profile_sample` (name -> n) are
+        launched hundreds of times per step: only every n-th launch is bracketed (two event records per launch
+        would otherwise perturb what they measure); `collect_profile` scales the sampled average to all launches."""
+        if self.profile is None:
+            return _NO_TIMER
+        every = self.profile_sample.get(name, 1)
+        if every > 1:
+            k = self._sample_count.get(name, 0)
+            self._sample_count[name] = k + 1
+            if k % every:
+                return _NO_TIMER
+        return _Timer(self, name)
 
     def collect_profile(self) -> dict:
         torch.cuda.synchronize()
         out = {}
         for name, evs in (self.profile or {}).items():
-            out[name] = {"ms_total": float(sum(a.elapsed_time(b) for a, b in evs)), "launches": len(evs)}
+            timed_ms = float(sum(a.elapsed_time(b) for a, b in evs))
+            launches = self._sample_count.get(name, len(evs)) if self.profile_sample.get(name, 1) > 1 else len(evs)
+            out[name] = {"ms_total": timed_ms * launches / max(len(evs), 1), "launches": launches, "timed_launches": len(evs)}
+        self._sample_count = {}
         return out
 
     # ------------------------------------------------------------------ objects

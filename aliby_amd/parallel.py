@@ -45,6 +45,9 @@ def gather_rows(values: torch.Tensor, meta: torch.Tensor, dst: int = 0, group=No
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return values, meta
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out_dev = values.device
+    if dist.get_backend(group) == "gloo" and values.is_cuda:  # gloo moves host memory; RCCL moves device memory directly
+        values, meta = values.cpu(), meta.cpu()
     dev = values.device
     n_local = torch.tensor([values.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -65,7 +68,7 @@ def gather_rows(values: torch.Tensor, meta: torch.Tensor, dst: int = 0, group=No
     dist.gather(pm, bm, dst=dst, group=group)
     if rank != dst:
         return None, None
-    return (torch.cat([b[:c] for b, c in zip(bv, counts)], 0), torch.cat([b[:c] for b, c in zip(bm, counts)], 0))
+    return (torch.cat([b[:c] for b, c in zip(bv, counts)], 0).to(out_dev), torch.cat([b[:c] for b, c in zip(bm, counts)], 0).to(out_dev))
 
 
 def barrier():

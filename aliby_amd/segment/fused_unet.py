@@ -74,8 +74,7 @@ class FusedUNet:
         assert dtype == torch.bfloat16, "the fused kernels are bf16"
         self.eng, self.dtype = eng, dtype
         self.mfma_levels = tuple(mfma_levels)
-        self.conv_bytes = 0  # algorithmic bytes / flops of the MFMA conv launches while profiling is on
-        self.conv_flops = 0
+        self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
         self.lib, self.h = eng.lib, eng.ctx.handle
         net = net.float().eval()
         self.down = []
@@ -126,9 +125,10 @@ class FusedUNet:
         if act is not None:
             sh = shift if shift is not None else act.shift
             per_sample = self._sps(sh)
-        if self.eng.profile is not None:
+        timer = self.eng.timed("fused_pointwise")
+        if timer.active:
             self.bytes_moved += 2 * (A.numel() + (B.numel() if B is not None else 0) + (n * c * H * W) * ((S is not None) + (T is not None)))
-        with self.eng.timed("fused_pointwise"):
+        with timer:
           _lib.check(self.lib.aliby_nn_fused_act_bf16(
             self.h, _ptr(A), _ptr(B) if B is not None else 0, _ptr(S) if S is not None else 0, _ptr(T) if T is not None else 0,
             _ptr(bias) if bias is not None else 0,
@@ -181,12 +181,17 @@ class FusedUNet:
         sh = unit.shift if shift is None else shift
         sh = sh[..., k0:k1]
         scale = unit.scale[k0:k1]
-        if self.eng.profile is not None:
+        # two timing groups: the 32/64-output-channel launches are HBM-bound (144-288 FLOP/B), the 128-output-channel
+        # ones of the deep levels (576+ FLOP/B) are bound by the matrix cores
+        group = "conv3x3_mfma_deep" if cout >= 128 else "conv3x3_mfma"
+        timer = self.eng.timed(group)
+        if timer.active:  # algorithmic bytes / flops of exactly the launches that are bracketed with events
             px_out = n * H * W
-            self.conv_bytes += 2 * (x.numel() * cin // ctot + px_out * cout + (res.numel() * cout // cout_tot if res is not None else 0)
-                                    + (px_out // 4 * cout if pooled is not None else 0))
-            self.conv_flops += 2 * 9 * cin * cout * px_out
-        with self.eng.timed("conv3x3_mfma"):
+            st = self.conv_stats.setdefault(group, [0, 0])
+            st[0] += 2 * (x.numel() * cin // ctot + px_out * cout + (res.numel() * cout // cout_tot if res is not None else 0)
+                          + (px_out // 4 * cout if pooled is not None else 0))
+            st[1] += 2 * 9 * cin * cout * px_out
+        with timer:
             _lib.check(self.lib.aliby_nn_conv3x3_bf16(
                 self.h, _ptr(x), _ptr(unit.wpk[key]), _ptr(out), _ptr(scale), _ptr(sh), self._sps(sh),
                 _ptr(bias[n0:n1]) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
@@ -301,9 +306,10 @@ class FusedUNet:
         for the output shape, so the (possibly low-res) projection goes in slot B."""
         n, c, H, W = c1.shape
         S, T = self._new(n, c, H, W), self._new(n, c, H, W)
-        if self.eng.profile is not None:
+        timer = self.eng.timed("fused_pointwise")
+        if timer.active:
             self.bytes_moved += 2 * (c1.numel() + p_low.numel() + 2 * c1.numel())
-        with self.eng.timed("fused_pointwise"):
+        with timer:
           _lib.check(self.lib.aliby_nn_fused_act_bf16(
             self.h, _ptr(c1), _ptr(p_low), _ptr(S), _ptr(T), _ptr(bias), _ptr(unit.scale), _ptr(shift), n, H, W, c, 0,
             1 if up else 0, 1, self._sps(shift),

@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--net-dtype", default="bfloat16", choices=["bfloat16", "float32", "float16"])
     ap.add_argument("--net-batch", type=int, default=288, help="224x224 tiles per U-Net forward (the reference's batch_size knob)")
+    ap.add_argument("--time-every", type=int, default=7, help="bracket every n-th launch of the per-layer network kernels with HIP "
+                    "events (they are launched ~600 times per step; 1 = every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -103,8 +105,12 @@ def main():
     from aliby_amd import _lib, parallel, synth
 
     rank, world, local_rank = parallel.rank_world()
+    # ALIBY_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives go through host memory); the driver's runs use the default, RCCL ("nccl") with one GPU per rank
+    backend = os.environ.get("ALIBY_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
-    parallel.init("nccl" if world > 1 else None)
+    parallel.init(backend if world > 1 else None)
     dist = torch.distributed if world > 1 else None
 
     from aliby_amd.extraction.batch import extract_batch
@@ -166,9 +172,11 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.profile = {}
+    eng.profile_sample = {"conv3x3_mfma": args.time_every, "conv3x3_mfma_deep": args.time_every, "fused_pointwise": args.time_every}
+    eng._sample_count = {}
     if model.fused is not None:
         model.fused.bytes_moved = 0
-        model.fused.conv_bytes = model.fused.conv_flops = 0
+        model.fused.conv_stats = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,6 +185,8 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if backend != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.collect_profile()
@@ -200,10 +210,11 @@ def main():
     launches = hip_groups[dominant]["launches"]
     avg_ms = hip_groups[dominant]["ms_total"] / launches
     ab = alg_bytes(dominant, B, C, Z, Y, X, table.n_obj, n_tiles_net)
-    if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the launches
-        ab = model.fused.bytes_moved / launches
-    if dominant == "conv3x3_mfma":  # exact: input + residual read once, output written once, per launch
-        ab = model.fused.conv_bytes / launches
+    timed_launches = hip_groups[dominant].get("timed_launches", launches)
+    if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the timed launches
+        ab = model.fused.bytes_moved / timed_launches
+    if dominant.startswith("conv3x3_mfma"):  # exact: input + residual read once, output (+ pooled) written once, per timed launch
+        ab = model.fused.conv_stats[dominant][0] / timed_launches
     achieved = ab / (avg_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     # FETCH_SIZE doubled on gfx950): measured offline, committed under profiles/, see profiles/pmc_traffic.json
@@ -214,10 +225,22 @@ def main():
     roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
             "avg_launch_ms": round(avg_ms, 4), "launches": launches}
-    if dominant == "conv3x3_mfma":  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
-        roof["mfma_tflops"] = round(model.fused.conv_flops / launches / (avg_ms * 1e-3) / 1e12, 1)
+    if dominant.startswith("conv3x3_mfma"):  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
+        roof["mfma_tflops"] = round(model.fused.conv_stats[dominant][1] / timed_launches / (avg_ms * 1e-3) / 1e12, 1)
+    roof["timed_launches"] = timed_launches
+    # the deep levels' launches of the same kernel (128 output channels, K/N-split): bound by the matrix cores
+    roof_deep = None
+    if "conv3x3_mfma_deep" in prof and prof["conv3x3_mfma_deep"].get("timed_launches"):
+        g = prof["conv3x3_mfma_deep"]
+        st = model.fused.conv_stats["conv3x3_mfma_deep"]
+        t_ms = g["ms_total"] / g["launches"]
+        tf = st[1] / g["timed_launches"] / (t_ms * 1e-3) / 1e12
+        roof_deep = {"bound": "mfma", "kernel": "conv3x3_mfma_deep", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(t_ms, 4), "launches": g["launches"],
+                     "timed_launches": g["timed_launches"],
+                     "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
     net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(args.steps, 1)
-    hip_in_net_ms = (prof.get("fused_pointwise", {}).get("ms_total", 0.0) + prof.get("conv3x3_mfma", {}).get("ms_total", 0.0)) / max(args.steps, 1)
+    hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "out_head")) / max(args.steps, 1)
     net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
     mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,
             "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3}
@@ -254,6 +277,7 @@ def main():
                 "gathered_rows": int(gv.shape[0]) if gv is not None else None,
             },
             "roofline": roof,
+            "roofline_mfma": roof_deep,
             "cpu_baseline": cpu,
             "mfma": mfma,
             "kernel_ms_per_step": {k: round(v["ms_total"] / args.steps, 3) for k, v in prof.items()},

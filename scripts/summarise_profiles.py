@@ -44,7 +44,14 @@ for which, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         k = short(r["Kernel_Name"])
         t = traffic.setdefault(k, {"FETCH_SIZE": [], "WRITE_SIZE": []})
         t[col].append(float(r["Counter_Value"]))
-groups = {"conv3x3_mfma": "k_conv3x3", "fused_pointwise": "k_fused_act", "out_head": "k_out_head"}
+def conv_group(k):  # same split as fused_unet._launch_unit: 128-output-channel launches are the compute-bound group
+    if not k.startswith("k_conv3x3"):
+        return None
+    return "conv3x3_mfma_deep" if ", 128," in k else "conv3x3_mfma"
+
+
+groups = {"conv3x3_mfma": lambda k: conv_group(k) == "conv3x3_mfma", "conv3x3_mfma_deep": lambda k: conv_group(k) == "conv3x3_mfma_deep",
+          "fused_pointwise": lambda k: k.startswith("k_fused_act"), "out_head": lambda k: k.startswith("k_out_head")}
 out = {}
 with open(f"profiles/{tag}_pmc_hbm_traffic_summary.csv", "w") as f:
     w = csv.writer(f)
@@ -54,11 +61,11 @@ with open(f"profiles/{tag}_pmc_hbm_traffic_summary.csv", "w") as f:
             continue
         fa = sum(t["FETCH_SIZE"]) / len(t["FETCH_SIZE"]); wa = sum(t["WRITE_SIZE"]) / len(t["WRITE_SIZE"])
         w.writerow([k, len(t["FETCH_SIZE"]), round(fa, 1), round(wa, 1), round((2 * fa + wa) * 1024)])
-for g, prefix in groups.items():
-    fs = [v for k, t in traffic.items() if k.startswith(prefix) for v in t["FETCH_SIZE"]]
-    ws = [v for k, t in traffic.items() if k.startswith(prefix) for v in t["WRITE_SIZE"]]
+for g, match in groups.items():
+    fs = [v for k, t in traffic.items() if match(k) for v in t["FETCH_SIZE"]]
+    ws = [v for k, t in traffic.items() if match(k) for v in t["WRITE_SIZE"]]
     if fs and ws:
-        out[g] = {"kernel": prefix + "*", "launches": len(fs), "fetch_size_kb_per_launch": sum(fs) / len(fs),
+        out[g] = {"kernel": ", ".join(sorted(k.split("(")[0] for k in traffic if match(k)))[:300], "launches": len(fs), "fetch_size_kb_per_launch": sum(fs) / len(fs),
                   "write_size_kb_per_launch": sum(ws) / len(ws),
                   "hbm_bytes_per_launch": (2 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024,
                   "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1`; "
