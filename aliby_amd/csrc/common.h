@@ -22,6 +22,7 @@ struct aliby_ctx {
 
 void aliby_set_error(const char* fmt, ...);
 int aliby_ensure_scratch(aliby_ctx* ctx, size_t bytes);
+int aliby_wait_stream(hipStream_t s);
 
 #define HIP_TRY(expr)                                                              \
   do {                                                                             \

@@ -656,7 +656,7 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
   hipLaunchKernelGGL(k_apply_ids, dim3(gP), dim3(256), 0, s, M0, newid, sh, labels_out);
   KERNEL_CHECK();
   HIP_TRY(hipMemcpyAsync(n_labels_host, ntot, sizeof(int) * F, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   int n_obj = 0;
   for (int f = 0; f < F; ++f) {
     if (n_labels_host[f] >= 65535) {
@@ -747,7 +747,7 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
   hipLaunchKernelGGL(k_to_u16, dim3(gP), dim3(256), 0, s, out32, totP, labels_out);
   KERNEL_CHECK();
   HIP_TRY(hipMemcpyAsync(n_labels_host, nfinal, sizeof(int) * F, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   delete[] offsets;
   delete[] tab_host;
   delete[] nit;

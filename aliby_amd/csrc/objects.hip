@@ -175,7 +175,7 @@ int aliby_label_max(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
   hipLaunchKernelGGL(k_label_max, dim3(bx, F), dim3(256), 0, s, labels, plane, d);
   KERNEL_CHECK();
   HIP_TRY(hipMemcpyAsync(max_host, d, sizeof(int) * (size_t)F, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   return ALIBY_OK;
 }
 
@@ -203,7 +203,7 @@ int aliby_object_table(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int
   if (table_host) {
     HIP_TRY(hipMemcpyAsync(table_host, table_dev, sizeof(aliby_object) * (size_t)n_obj,
                            hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   }
   return ALIBY_OK;
 }
@@ -234,7 +234,7 @@ int aliby_relabel_sequential(aliby_ctx* ctx, uint16_t* labels, int F, int Y, int
   hipLaunchKernelGGL(k_apply_map, dim3(bx, F), dim3(256), 0, s, labels, plane, map);
   KERNEL_CHECK();
   HIP_TRY(hipMemcpyAsync(n_host, cnt, b_cnt, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   for (int f = 0; f < F; ++f) {
     if (n_host[f] >= 65535) {
       aliby_set_error("Segmentation produced %d labels; uint16 cast unsafe.", n_host[f]);

@@ -170,7 +170,7 @@ int aliby_crop_pad_u16(aliby_ctx* ctx, const uint16_t* stack, int C, int Z, int 
     KERNEL_CHECK();
   }
   // rects/flags live in ctx scratch: make sure the copies are consumed before the host reuses it
-  HIP_TRY(hipStreamSynchronize(s));
+  { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   return ALIBY_OK;
 }
 

@@ -136,7 +136,7 @@ class FeatureEngine:
             pool[key] = buf
         view = buf[:need].view(t.shape)
         view.copy_(t.contiguous(), non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        _lib.check(self.lib.aliby_stream_sync(self.ctx.handle, _stream_ptr()))  # polls an event: no late wake-up
         return view.numpy().copy() if copy else view.numpy()
 
     # ---------------------------------------------------------------- profiling

@@ -128,6 +128,64 @@ def register_optional(eng_cls):
                                            launch=_launch_radial_distribution, needs_pixels=True)
 
 
+class _FanOut:
+    """Per-object kernels are one small workgroup per object: latency-bound and far from filling 256 CUs, so
+    independent instructions (different channels / families / channel pairs) go to a few side HIP streams and run
+    concurrently.  fork(): side streams wait for the main stream; join(): the main stream waits for them.  Only
+    taken when every object window is LDS-resident (the global-scratch variants share the context's scratch)."""
+
+    def __init__(self, eng, table, out):
+        import os
+
+        n = int(os.environ.get("ALIBY_FEATURE_STREAMS", "4"))
+        small = table.n_obj > 0 and table.max_h * table.max_w <= 4096
+        self.enabled = n > 1 and small and out.is_cuda
+        self.out = out
+        self.k = 0
+        if self.enabled:
+            pool = eng.__dict__.setdefault("_side_streams", [])
+            while len(pool) < n:
+                pool.append(torch.cuda.Stream())
+            self.streams = pool[:n]
+            self.used = set()
+
+    def fork(self):
+        if self.enabled:
+            ev = torch.cuda.Event()
+            ev.record()
+            for st in self.streams:
+                st.wait_event(ev)
+
+    def next_stream(self):
+        if not self.enabled:
+            return _NULL_CTX
+        i = self.k % len(self.streams)
+        self.k += 1
+        self.used.add(i)
+        self.out.record_stream(self.streams[i])
+        return torch.cuda.stream(self.streams[i])
+
+    def join(self):
+        if self.enabled:
+            main = torch.cuda.current_stream()
+            for i in sorted(self.used):
+                ev = torch.cuda.Event()
+                ev.record(self.streams[i])
+                main.wait_event(ev)
+            self.used.clear()
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=False):
     """Run every instruction over every object; returns (matrix [n_obj, n_cols] on device, blocks)."""
     register_optional(type(eng))
@@ -146,6 +204,7 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
     out = eng.new_output(table.n_obj, col)
     cache = PlaneCache(eng, planes) if planes is not None else None
 
+    fan = _FanOut(eng, table, out)
     if multi:
         # one launch per (pair, red_z): every requested colocalisation metric of that pair together
         groups = {}
@@ -162,26 +221,64 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
             g["scale_max"] = kw.get("scale_max", g["scale_max"])
         if cache is None:
             raise Exception("pixels are required for colocalisation instructions")
+        for ((ch0, ch1), red_z), g in groups.items():  # shared inputs first, on the main stream: z-reduction, rank planes
+            plane, dt = cache.get(red_z)
+            if "rwc" in g["cols"]:
+                eng.rank_planes(labels, plane, dt, table, (ch0, ch1))
+        fan.fork()
         for ((ch0, ch1), red_z), g in groups.items():
             plane, dt = cache.get(red_z)
-            eng.coloc(labels, plane, dt, ch0, ch1, table, out, g["cols"], thr=g["thr"], scale_max=g["scale_max"])
+            with fan.next_stream():
+                eng.coloc(labels, plane, dt, ch0, ch1, table, out, g["cols"], thr=g["thr"], scale_max=g["scale_max"])
+        fan.join()
         return out, blocks
 
-    done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
-    cell_cache = {}
+    # shared, pixel-independent inputs first, on the main stream (each is cached on the object table)
     for inst, reg, kw, col0, ncols in specs:
+        metric = inst[-1]
+        if inst[0] != "None" and reg["needs_pixels"] and cache is not None and inst[1] in _RED:
+            cache.get(inst[1])
+        if metric in ("zernike", "radial_zernikes") and table.n_obj:
+            eng.mec(labels, table)
+        if metric == "radial_distribution" and table.n_obj and kw.get("scaled", True):
+            eng.radial_geometry(labels, table, kw.get("bin_count", 4))
+    fan.fork()
+    done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
+    copies, after = [], []
+    cell_cache = {}
+    for spec in specs:
+        inst, reg, kw, col0, ncols = spec
         ch, red_z, metric = inst[0], inst[1], inst[-1]
-        extra = {"cell_cache": cell_cache} if reg.get("cell") else {}
+        if reg.get("cell"):
+            after.append(spec)  # cell.py metrics share a cached block: main stream, after the join
+            continue
         if ch == "None" or not reg["needs_pixels"]:
             if ch != "None" and cache is not None:
                 cache.get(red_z)  # the reference would still reduce (and raise on a bad reducer)
             key = (metric, tuple(sorted(kw.items())))
             if key in done:
                 # e.g. "feret"/"zernike" listed under every channel: same labels, same numbers
-                out[:, col0 : col0 + ncols] = out[:, done[key] : done[key] + ncols]
+                copies.append((col0, done[key], ncols))
             else:
-                reg["launch"](eng, labels, table, None, 0, None, out, col0, kw, **extra)
+                with fan.next_stream():
+                    reg["launch"](eng, labels, table, None, 0, None, out, col0, kw)
                 done[key] = col0
+        else:
+            if cache is None:
+                raise Exception("pixels are required for this instruction")
+            plane, dt = cache.get(red_z)
+            with fan.next_stream():
+                reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw)
+    fan.join()
+    for col0, src, ncols in copies:
+        out[:, col0 : col0 + ncols] = out[:, src : src + ncols]
+    for inst, reg, kw, col0, ncols in after:
+        ch, red_z = inst[0], inst[1]
+        extra = {"cell_cache": cell_cache}
+        if ch == "None" or not reg["needs_pixels"]:
+            if ch != "None" and cache is not None:
+                cache.get(red_z)
+            reg["launch"](eng, labels, table, None, 0, None, out, col0, kw, **extra)
         else:
             if cache is None:
                 raise Exception("pixels are required for this instruction")
