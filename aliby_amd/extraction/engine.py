@@ -88,6 +88,16 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 
 
+class _Download:
+    def __init__(self, event, views):
+        self.event, self.views = event, views
+
+    def wait(self):
+        while not self.event.query():  # polled (see aliby_wait_stream): no late wake-up
+            pass
+        return [v.numpy() for v in self.views]
+
+
 class _Timer:
     __slots__ = ("eng", "name", "a")
     active = True
@@ -138,6 +148,31 @@ class FeatureEngine:
         view.copy_(t.contiguous(), non_blocking=True)
         _lib.check(self.lib.aliby_stream_sync(self.ctx.handle, _stream_ptr()))  # polls an event: no late wake-up
         return view.numpy().copy() if copy else view.numpy()
+
+    def to_host_async(self, tensors, slot: int = 0):
+        """Start the download of `tensors` into pinned buffers on a side stream (after everything queued so far on the
+        current stream) and return a handle; handle.wait() -> list of NumPy views.  The copy overlaps whatever the
+        caller queues next; `slot` selects one of the reusable buffer sets (alternate it between consecutive calls)."""
+        side = self.__dict__.setdefault("_copy_stream", None) or torch.cuda.Stream()
+        self._copy_stream = side
+        pool = self.__dict__.setdefault("_pinned_async", {})
+        done = torch.cuda.Event()
+        ready = torch.cuda.Event()
+        ready.record()
+        side.wait_event(ready)
+        views = []
+        with torch.cuda.stream(side):
+            for i, t in enumerate(tensors):
+                key = (slot, i, t.dtype)
+                buf = pool.get(key)
+                if buf is None or buf.numel() < t.numel():
+                    buf = pool[key] = torch.empty(int(t.numel() * 1.25) + 1024, dtype=t.dtype, pin_memory=True)
+                v = buf[: t.numel()].view(t.shape)
+                v.copy_(t, non_blocking=True)
+                t.record_stream(side)
+                views.append(v)
+            done.record(side)
+        return _Download(done, views)
 
     # ---------------------------------------------------------------- profiling
     def timed(self, name: str):

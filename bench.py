@@ -158,9 +158,12 @@ def main():
         planes = (px, _lib.U16)
         m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
         m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
-        with eng.timed("rows_d2h"):
-            rows = (torch.from_numpy(eng.to_host(m1, copy=False)), torch.from_numpy(eng.to_host(m2, copy=False)))
-        return rows, table, model.last_counts
+        # rows -> pinned host memory on a side stream: the download of step k overlaps the start of step k+1
+        pending = eng.to_host_async((m1, m2), slot=step.parity)
+        step.parity ^= 1
+        return pending, table, model.last_counts
+
+    step.parity = 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -170,7 +173,7 @@ def main():
 
     eng.profile = None
     for _ in range(args.warmup):
-        step()
+        step()[0].wait()
     eng.profile = {}
     eng.profile_sample = {"conv3x3_mfma": args.time_every, "conv3x3_mfma_deep": args.time_every, "fused_pointwise": args.time_every}
     eng._sample_count = {}
@@ -179,8 +182,13 @@ def main():
         model.fused.conv_stats = {}
     barrier()
     t0 = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
-        rows, table, counts = step()
+        nxt, table, counts = step()
+        if pending is not None:
+            pending.wait()  # the previous step's rows are on the host (its buffers may be reused two steps later)
+        pending = nxt
+    rows = tuple(torch.from_numpy(a) for a in pending.wait())  # the last step's rows land inside the timed region too
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
