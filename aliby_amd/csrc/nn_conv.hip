@@ -319,9 +319,10 @@ struct DmaCfg {
   // CIN = 128: the 288 weight VGPRs of a wave only fit the 512-register budget of ONE wave per SIMD; the DMA
   // pipeline (next window in flight during the MFMA loop) is what keeps that single wave fed
   static constexpr int WAVES_PER_SIMD = CIN >= 128 ? 1 : 2;
-  static constexpr int R = CIN >= 128 ? 4 : (CIN >= 64 ? 2 : 4);
+  static constexpr int R = CIN >= 64 ? 2 : 4;      // output rows per wave and pass
+  static constexpr int PASSES = CIN >= 128 ? 2 : 1;  // row passes per tile (accumulators reused): a taller tile, less halo
   static constexpr int RG = 4 / NCB;
-  static constexpr int TH = RG * R, TW = 32, LH = TH + 2, LW = TW + 2;
+  static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2;
   static constexpr int RAW = LH * LW;
   static constexpr int PLANE = NPL == 4 ? RAW + (10 - RAW % 8) % 8 : (RAW | 1);
   static constexpr int A_SLOTS = NPL * PLANE;
@@ -340,7 +341,7 @@ template <int CIN, int COUT, bool UP>
 __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void k_conv3x3_dma(ConvArgs a) {
   using cfg = DmaCfg<CIN, COUT, UP>;
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
-  constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, RLW = cfg::RLW;
+  constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, RLW = cfg::RLW, PASSES = cfg::PASSES;
   constexpr int PIX_PER_IT = cfg::PIX_PER_IT, ITERS = cfg::ITERS, GIT = cfg::GIT;
   extern __shared__ uint4 lds[];
   uint4* const ldsA = lds;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int gx = x0 + px, rbase = rg * R;
+    const int gx = x0 + px;
 
     // ---- everything this tile needs from global memory besides the window: requested before the DMA wait
     f32x2_t sh[4];
@@ -411,17 +412,18 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       for (int q = 0; q < 4; ++q) b4[q] = bp[q];
     }
     uint4 rr[R][2];
-    if (a.res) {
+    auto load_res = [&](int pass) {
       const int RH = a.H >> a.res_up, RWd = a.W >> a.res_up;
       const uint4* resN = a.res + (size_t)n * RH * RWd * a.ocs + a.ocoff;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const int cy = min(y0 + rbase + r, a.H - 1), cx = min(gx, a.W - 1);
+        const int cy = min(y0 + (rg * PASSES + pass) * R + r, a.H - 1), cx = min(gx, a.W - 1);
         const unsigned off = (unsigned)(((cy >> a.res_up) * RWd + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
         rr[r][0] = resN[off];
         rr[r][1] = resN[off + 1];
       }
-    }
+    };
+    if (a.res) load_res(0);
     CONV_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
     __syncthreads();                                   // ... and everyone's; the previous tile's reads of A are over
@@ -447,56 +449,61 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
     }
     CONV_STAMP(3);
     __syncthreads();
-    // ---- seed the accumulators with bias + residual
-    f32x16_t acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
-      }
-      if (a.res) {
-        const unsigned rw[8] = {rr[r][0].x, rr[r][0].y, rr[r][0].z, rr[r][0].w, rr[r][1].x, rr[r][1].y, rr[r][1].z, rr[r][1].w};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
-          acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int rbase = (rg * PASSES + pass) * R;
+      // ---- seed the accumulators with bias + residual
+      f32x16_t acc[R];
+  #pragma unroll
+      for (int r = 0; r < R; ++r) {
+  #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
+        }
+        if (a.res) {
+          const unsigned rw[8] = {rr[r][0].x, rr[r][0].y, rr[r][0].z, rr[r][0].w, rr[r][1].x, rr[r][1].y, rr[r][1].z, rr[r][1].w};
+  #pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
+            acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
+          }
         }
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (tile + nslots < t_end) issue_dma(tile + nslots);  // R is free: everyone passed the barrier after the prologue
-    __builtin_amdgcn_sched_barrier(0);
-    CONV_STAMP(4);
-    // ---- implicit GEMM (as in k_conv3x3)
-    const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px;
-    constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
-    bf16x8_t ring[DEPTH];
-    auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
-#pragma unroll
-    for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
-    static_for<NF>([&](auto fc) {
-      constexpr int f = decltype(fc)::value;
-      if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
-      constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
-      static_for<3>([&](auto dc) {
-        constexpr int dy = decltype(dc)::value, r = ir - dy;
-        if constexpr (r >= 0 && r < R)
-          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
-      });
       __builtin_amdgcn_sched_barrier(0);
-    });
-    CONV_STAMP(5);
-    if (gx < a.W) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int gy = y0 + rbase + r;
-        if (gy >= a.H) continue;
-        uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
-        op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
-                           cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
-        op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
-                           cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
+      if (pass == 0 && tile + nslots < t_end) issue_dma(tile + nslots);  // R is free: everyone passed the barrier after the prologue
+      if (pass + 1 < PASSES && a.res) load_res(pass + 1);                   // consumed after this pass's MFMA loop
+      __builtin_amdgcn_sched_barrier(0);
+      if (pass == 0) CONV_STAMP(4);
+      // ---- implicit GEMM (as in k_conv3x3)
+      const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px;
+      constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
+      bf16x8_t ring[DEPTH];
+      auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
+  #pragma unroll
+      for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
+      static_for<NF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
+        constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
+        static_for<3>([&](auto dc) {
+          constexpr int dy = decltype(dc)::value, r = ir - dy;
+          if constexpr (r >= 0 && r < R)
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (pass == PASSES - 1) CONV_STAMP(5);
+      if (gx < a.W) {
+  #pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int gy = y0 + rbase + r;
+          if (gy >= a.H) continue;
+          uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
+          op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
+                             cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
+          op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
+                             cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
+        }
       }
     }
     CONV_STAMP(6);
@@ -616,6 +623,7 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   if (CIN == 64 && COUT == 64 && !in_up) return launch_conv<64, 64, false>(ctx, a, stream);
   if (CIN == 64 && COUT == 64 && in_up) return launch_conv<64, 64, true>(ctx, a, stream);
   if (CIN == 64 && COUT == 128) return in_up ? launch_conv<64, 128, true>(ctx, a, stream) : launch_conv<64, 128, false>(ctx, a, stream);
+  if (CIN == 128 && COUT == 128 && !a.pool) return in_up ? launch_conv_dma<128, 128, true>(ctx, a, stream) : launch_conv_dma<128, 128, false>(ctx, a, stream);
   if (CIN == 32 && COUT == 64 && !in_up) return launch_conv<32, 64, false>(ctx, a, stream);
   aliby_set_error("conv3x3: unsupported (CIN=%d, COUT=%d, upsample=%d) combination", CIN, COUT, in_up);
   return ALIBY_ERR_UNSUPPORTED;

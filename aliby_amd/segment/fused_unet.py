@@ -66,6 +66,8 @@ class _Proj:
 
 # (CIN, COUT, input read through the 2x upsample) instantiations of k_conv3x3
 _MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True), (64, 128, False), (64, 128, True)}
+# (the library also instantiates (128, 128, *) — one wave per SIMD with 288 weight registers — which measured no faster
+# than two 64-channel K-slices and is not used here)
 _POOL_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 128, False)}
 
 
@@ -149,11 +151,11 @@ class FusedUNet:
         H, W = (x.shape[2] * 2, x.shape[3] * 2) if in_up else (x.shape[2], x.shape[3])
         out = self._new(n, cout, H, W)
         pooled = self._new(n, cout, H // 2, W // 2) if pool else None
-        if (cin, cout, bool(in_up)) in _MFMA_SHAPES:
+        if (cin, cout, bool(in_up)) in (_POOL_SHAPES if pool else _MFMA_SHAPES):
             self._launch_unit(x, unit, (0, cin), (0, cout), out, shift, bias, res, res_up, in_up, pooled)
             return (out, pooled) if pool else out
-        ks = 64 if cin > 64 else cin
         ns = 128 if cout > 128 else cout
+        ks = 64 if cin > 64 else cin
         assert cin % ks == 0 and cout % ns == 0 and (ks, ns, bool(in_up)) in _MFMA_SHAPES, (cin, cout, in_up)
         for n0 in range(0, cout, ns):
             cur, cur_up = res, res_up

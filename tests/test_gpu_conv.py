@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True), (64, 128, False), (64, 128, True)]
+COMBOS = [(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True), (64, 128, False), (64, 128, True), (128, 128, False), (128, 128, True)]
 
 
 def _run(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W, pool=None):
@@ -62,19 +62,20 @@ def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up, shape):
     n, H, W = shape  # neither multiples of the tile height nor of the 32-pixel strip; images smaller than one tile
     ih, iw = (H // 2, W // 2) if in_up else (H, W)
     x = torch.randint(-1, 3, (n, ih, iw, cin), generator=g).to(torch.bfloat16).cuda()
-    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
+    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < (0.15 if cin < 128 else 0.07))).float().cuda()
     scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
     shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
     bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
     res = torch.randint(-3, 4, (n, H // 2, W // 2, cout), generator=g).to(torch.bfloat16).cuda()
-    pool = torch.full((n, H // 2, W // 2, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    pool = torch.full((n, H // 2, W // 2, cout), float("nan"), dtype=torch.bfloat16, device="cuda") if cin < 128 else None
     out = _run(engine, x, w, scale, shift, bias, res, True, in_up, H, W, pool=pool)
     ref = _reference(x, w, scale, shift, bias, res, True, in_up)
     assert float(ref.abs().max()) <= 256  # exactly representable in bf16
     assert torch.equal(out.float(), ref)
     # fused max_pool2d(OUT, 2, 2): the next level's input
-    ref_pool = torch.nn.functional.max_pool2d(ref.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
-    assert torch.equal(pool.float(), ref_pool)
+    if pool is not None:
+        ref_pool = torch.nn.functional.max_pool2d(ref.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+        assert torch.equal(pool.float(), ref_pool)
 
 
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
