@@ -226,6 +226,21 @@ class FeatureEngine:
             max_area = max_h = max_w = 0
         return ObjectTable(dev, host, offsets, n_obj, max_area, max_h, max_w)
 
+    def track_stitch(self, prev: torch.Tensor, cur: torch.Tensor, prev_table: ObjectTable, cur_table: ObjectTable,
+                     prev_tracked: torch.Tensor | None, max_label: np.ndarray | None, threshold: float = 0.25):
+        """IoU stitching of two label stacks [F,Y,X] (aliby_track_stitch).  Returns (tracked label per current object row
+        as an int32 device tensor, new running maximum per tile as int32 [F])."""
+        F, Y, X = cur.shape
+        tracked = torch.zeros(max(cur_table.n_obj, 1), dtype=torch.int32, device=cur.device)
+        mx_in = None if max_label is None else np.ascontiguousarray(max_label, dtype=np.int32)
+        mx_out = np.zeros(F, np.int32)
+        with self.timed("track_stitch"):
+            _lib.check(self.lib.aliby_track_stitch(
+                self.ctx.handle, _ptr(prev), _ptr(cur), F, Y, X, _ptr(cur_table.dev), _ptr(cur_table.offsets), _ptr(prev_table.dev),
+                _ptr(prev_table.offsets), _ptr(prev_tracked) if prev_tracked is not None else 0, _ptr(mx_in) if mx_in is not None else 0,
+                float(threshold), _ptr(tracked), _ptr(mx_out), _stream_ptr()))
+        return tracked[: cur_table.n_obj], mx_out
+
     def relabel_sequential(self, labels: torch.Tensor) -> np.ndarray:
         F, Y, X = labels.shape
         n = np.zeros(F, np.int32)

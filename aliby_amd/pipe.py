@@ -24,9 +24,10 @@ def _segmenter(step_name: str, parameters: dict, _initialised: dict) -> Callable
 
 
 def _tracker(step_name: str, parameters: dict, _initialised: dict) -> Callable:
-    raise NotImplementedError(
-        "the reference's 'stitch' tracker is broken/deprecated (src/aliby/track/trackers.py:11,75,87; SURVEY §2 row 15)"
-    )
+    """`dispatch_tracker(**parameters)` like the reference (pipe.py:41-44); the `stitch` kind is the HIP IoU stitcher."""
+    from aliby_amd.track.stitch import dispatch_tracker
+
+    return dispatch_tracker(**parameters)
 
 
 # first matching prefix wins, in the reference's order (pipe.py:56-72)

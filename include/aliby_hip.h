@@ -165,6 +165,21 @@ int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void*
                           const float* shift, int shift_per_sample, const float* bias, const void* res,
                           int res_up, int N, int H, int W, int CIN, int COUT, int in_up, int in_channels,
                           int in_channel0, int out_channels, int out_channel0, void* pool_out, void* stream);
+/* Frame-to-frame IoU stitching of label images, batched over tiles: the working stand-in for the reference's `stitch`
+ * tracker (src/aliby/track/trackers.py:14-90 = update_labels + cellpose.utils.stitch3D on a (previous, current) pair
+ * per tile; not importable as shipped).  prev / cur are uint16 [F,Y,X]; the tables and their host offsets come from
+ * aliby_object_table (rows in (tile, label) order); prev_tracked_dev[row] is the tracked label the previous frame's
+ * object already carries (NULL = its own label); max_label_in_host[tile] the running maximum (NULL = 0).
+ * cur_tracked_dev[row] receives the tracked label of every current object (0 for labels absent from the frame):
+ * the previous tracked label of the best IoU >= threshold partner that is also that partner's best, else
+ * max_label + 1, + 2, ... in current label order; max_label_out_host[tile] the new running maximum.
+ * threshold in [1/8, 1] (cellpose's default is 0.25). */
+int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const uint16_t* cur, int F, int Y, int X,
+                       const aliby_object* cur_table_dev, const int32_t* cur_offsets_host,
+                       const aliby_object* prev_table_dev, const int32_t* prev_offsets_host,
+                       const int32_t* prev_tracked_dev, const int32_t* max_label_in_host, double threshold,
+                       int32_t* cur_tracked_dev, int32_t* max_label_out_host, void* stream);
+
 /* Diagnostics: when stamps_dev != NULL, wave 0 of workgroup 0 of every following conv3x3 launch (register-staged
  * variant) writes its shader-clock stamps at the phase boundaries of its first 16 tiles into stamps_dev[16][8]
  * (uint64: 0 tile start, 1 loads issued, 2 after barrier, 3 prologue done, 4 after barrier, 5 MFMA done,

@@ -204,3 +204,103 @@ def test_cell_py_metrics_match_reference_restatement(engine):
         process_tree_masks({"None": {"None": ["no_such_metric"]}}, masks, pixels, extract_tree)
     with pytest.raises(Exception, match="invalid reducer"):
         process_tree_masks({0: {"mean": ["intensity"]}}, masks, pixels, extract_tree)
+
+
+def _blob_frames(seed, n_frames=4, shape=(96, 128), n_cells=9):
+    """Label images of drifting / appearing / vanishing discs (labels renumbered per frame like a segmenter would)."""
+    rng = np.random.default_rng(seed)
+    cy = rng.uniform(12, shape[0] - 12, n_cells); cx = rng.uniform(12, shape[1] - 12, n_cells); r = rng.uniform(5, 9, n_cells)
+    yy, xx = np.mgrid[: shape[0], : shape[1]]
+    frames = []
+    for t in range(n_frames):
+        alive = rng.random(n_cells) > 0.15
+        lab = np.zeros(shape, np.uint16)
+        order = rng.permutation(n_cells)
+        k = 0
+        for i in order:
+            if not alive[i]:
+                continue
+            m = (yy - cy[i]) ** 2 + (xx - cx[i]) ** 2 <= r[i] ** 2
+            if (lab[m] > 0).any():
+                continue
+            k += 1
+            lab[m] = k
+        frames.append(lab)
+        cy += rng.normal(0, 1.5, n_cells); cx += rng.normal(0, 1.5, n_cells)
+    return frames
+
+
+def test_track_stitch_matches_oracle_over_a_time_lapse(engine):
+    """IoU stitcher through the C ABI vs the CPU restatement, tile-batched, state carried like the reference's track step."""
+    from aliby_amd.track.stitch import StitchTracker
+    from oracle.track_restated import stitch_rois as oracle_rois
+
+    tiles = [_blob_frames(s) for s in (1, 2, 3)]  # 3 tiles x 4 frames
+    trk = StitchTracker(engine=engine)
+    info_gpu = info_cpu = None
+    first = trk([[tile[0]] for tile in tiles])
+    assert all(first[k]["labels"] == list(range(1, int(tiles[k][0].max()) + 1)) for k in range(3))
+    for t in range(1, 4):
+        masks = [[tile[t - 1], tile[t]] for tile in tiles]
+        info_gpu = trk(masks, info_gpu)
+        info_cpu = oracle_rois(masks, info_cpu)
+        assert dict(info_gpu) == info_cpu, t
+        assert info_gpu["track_info"] is info_gpu  # what the engine's passed_data lookup relies on
+    # an identical frame pair keeps every label
+    same = trk([[tiles[0][1], tiles[0][1]]])
+    assert same[0]["labels"] == list(range(1, int(tiles[0][1].max()) + 1))
+
+
+def test_track_stitch_edge_cases(engine):
+    from aliby_amd.track.stitch import StitchTracker
+    from oracle.track_restated import stitch_rois as oracle_rois
+
+    trk = StitchTracker(engine=engine)
+    z = np.zeros((32, 32), np.uint16)
+    a = z.copy(); a[2:10, 2:10] = 1; a[20:30, 20:30] = 3  # label 2 absent from the frame
+    b = z.copy(); b[3:11, 3:11] = 2; b[0:2, 20:30] = 1
+    for masks in ([[z, z]], [[z, a]], [[a, z]], [[a, b]], [[b, a]]):
+        assert dict(trk(masks)) == oracle_rois(masks), masks
+    info = {0: {"labels": [5, 0, 9], "max_label": 12}}
+    assert dict(trk([[a, b]], info)) == oracle_rois([[a, b]], info)
+    with pytest.raises(ValueError):
+        StitchTracker(stitch_threshold=0.05, engine=engine)([[a, b]])
+
+
+def test_track_step_wired_through_the_engine(tmp_path, engine):
+    """The engine's own wiring (pipe_core.py:188-205): the `track` step gets the last two timepoints regrouped per tile
+    and, through passed_data, its own previous result as `track_info`."""
+    from aliby_amd.pipe import init_step
+    from aliby_amd.pipe_core import run_pipeline_return_state
+    from oracle.track_restated import stitch_rois as oracle_rois
+
+    tiles = [_blob_frames(s, n_frames=3) for s in (7, 8)]
+    clock = {"tp": 0}
+
+    def fake_segmenter(**kw):  # per-tile label images of the current timepoint, like a multi-tile segmenter's output
+        t = clock["tp"]
+        clock["tp"] += 1
+        return [tile[t] for tile in tiles]
+
+    def init(step_name, parameters, other_steps=None):
+        if step_name == "segment_cells":
+            return fake_segmenter
+        return init_step(step_name, parameters, other_steps)
+
+    pipeline = {
+        "ntps": 3,
+        "steps": {"segment_cells": {}, "track": {"kind": "stitch", "stitch_threshold": 0.25}},
+        "passed_data": {"track": [("masks", "segment_cells"), ("track_info", "track")]},
+        "retain": {"segment_cells": 2},
+    }
+    state = run_pipeline_return_state(pipeline, tmp_path, init)
+    got = state["data"]["track"]
+    want_info = None
+    for t in range(3):
+        masks = [[tile[t]] for tile in tiles] if t == 0 else [[tile[t - 1], tile[t]] for tile in tiles]
+        if t == 0:
+            want = {k: {"labels": list(range(1, int(tiles[k][0].max()) + 1)), "max_label": int(tiles[k][0].max())} for k in range(2)}
+        else:
+            want = oracle_rois(masks, want_info)
+        assert dict(got[t]) == want, t
+        want_info = want
