@@ -7,8 +7,8 @@ Mirrors src/aliby/tile/tiler.py: `dispatch_tiler` (56-72), `Tiler.from_image` (2
 aliby_amd/csrc/stager.hip through the C ABI (aliby_crop_pad_u16); the returned NumPy block is also
 registered in aliby_amd.devcache so that segment/extract steps reuse the device copy.
 
-Out of scope this round: trap detection (`segment_traps`) and drift estimation
-(`find_drift`, phase cross-correlation).  With `tile_size` set, tile centres must be given through
+Drift estimation (`find_drift`, phase cross-correlation) runs on the GPU when `calculate_drift` is set
+(aliby_amd/tile/drift.py).  Out of scope this round: trap detection (`segment_traps`).  With `tile_size` set, tile centres must be given through
 `trap_locations=[(y,x), ...]`; otherwise the reference's own fallback (one centre tile) is used.
 """
 
@@ -128,6 +128,22 @@ class Tiler:
         logging.getLogger("aliby").debug(f"Tiler.run_tp took {(perf_counter() - t1):.4f}s")
         return out
 
+    def find_drift(self, tp: int):
+        """Translational drift of frame `tp` against frame `tp - 1` on the reference channel / z plane
+        (tiler.py:284-307): phase cross-correlation on the GPU (aliby_amd/tile/drift.py)."""
+        from aliby_amd.tile.drift import phase_cross_correlation
+
+        ref_z = getattr(self, "ref_z", 0)
+        prev_tp = max(0, tp - 1)
+        drift = phase_cross_correlation(
+            np.asarray(self.pixels[prev_tp, self.ref_channel_index, ref_z]),
+            np.asarray(self.pixels[tp, self.ref_channel_index, ref_z]),
+        )
+        if 0 < tp < len(self.tile_locs.drifts):
+            self.tile_locs.drifts[tp] = drift.tolist()
+        else:
+            self.tile_locs.drifts.append(drift.tolist())
+
     def _run_tp(self, tp: int):
         if self.no_processed == 0:
             if hasattr(self, "ref_channel_index"):
@@ -141,12 +157,13 @@ class Tiler:
         if not hasattr(self, "calculate_drift"):
             self.calculate_drift = False
         if self.calculate_drift:
-            raise NotImplementedError("drift estimation (tiler.py:284-307) is SURVEY §8f-3 and not built")
-        drift = [0.0, 0.0]
-        if 0 < tp < len(self.tile_locs.drifts):
-            self.tile_locs.drifts[tp] = drift
+            self.find_drift(tp)
         else:
-            self.tile_locs.drifts.append(drift)
+            drift = [0.0, 0.0]
+            if 0 < tp < len(self.tile_locs.drifts):
+                self.tile_locs.drifts[tp] = drift
+            else:
+                self.tile_locs.drifts.append(drift)
         self.no_processed = tp + 1
         return {"drift": self.tile_locs.to_dict(tp), "pixels": self.get_fczyx(tp)}
 

@@ -304,3 +304,30 @@ def test_track_step_wired_through_the_engine(tmp_path, engine):
             want = oracle_rois(masks, want_info)
         assert dict(got[t]) == want, t
         want_info = want
+
+
+def test_drift_on_device_matches_fixture_and_moves_the_tiles(engine):
+    """Phase cross-correlation on the GPU vs the scikit-image fixture / the oracle, and the Tiler using it: with
+    calculate_drift the tile window follows the sample (tiles.py: centre - cumulative drift)."""
+    import json
+    from pathlib import Path
+
+    from aliby_amd.tile.drift import phase_cross_correlation
+    from aliby_amd.tile.tiler import Tiler, TilerParameters
+    from oracle.drift_restated import phase_cross_correlation as oracle_pcc
+    from tests.golden.make_golden import drift_cases
+
+    fx = json.loads((Path(__file__).parent / "golden" / "skimage_drift.json").read_text())
+    for (applied, ref, mov), rec in zip(drift_cases(), fx["cases"]):
+        assert phase_cross_correlation(ref, mov, normalization=None).tolist() == rec["shift"]
+        assert phase_cross_correlation(ref, mov).tolist() == oracle_pcc(ref, mov).tolist() == rec["shift"]
+    # a time lapse whose content moves by (+2, -3) px per frame
+    base = synth.make_fov(4, 0, shape=(160, 192), n_channels=1, n_z=1, n_target=10)["pixels"][:, 0]  # [C,Y,X]
+    T = 3
+    tczyx = np.stack([np.roll(base, (2 * t, -3 * t), axis=(1, 2)) for t in range(T)])[:, :, None]  # [T,C,1,Y,X]
+    tiler = Tiler(tczyx, {}, TilerParameters.default(tile_size=64, ref_channel=0), trap_locations=[(80, 96)])
+    tiler.calculate_drift = True
+    crops = [tiler.run_tp(t)["pixels"] for t in range(T)]
+    assert tiler.tile_locs.drifts == [[0.0, 0.0], [-2.0, 3.0], [-2.0, 3.0]]
+    # drift-corrected tiles show the same piece of the sample at every timepoint
+    assert all(np.array_equal(crops[0], c) for c in crops[1:])
