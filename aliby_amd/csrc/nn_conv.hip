@@ -90,6 +90,86 @@ struct ConvArgs {
       a.trace[stamp_tile * 8 + (slot_)] = __builtin_amdgcn_s_memtime();                     \
   } while (0)
 
+
+// ------------------------------------------------------------------------------------------------
+// Pieces shared by the two kernels below (register-staged and LDS-DMA window staging).
+// ------------------------------------------------------------------------------------------------
+
+// residual rows of one pass: R rows x 32 bytes per lane, from clamped addresses (rows / columns past the image edge
+// are loaded but never stored)
+template <int R>
+__device__ __forceinline__ void conv_load_res(const ConvArgs& a, int n, int row0, int gx, int c0, uint4 (&rr)[R][2]) {
+  const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
+  const uint4* resN = a.res + (size_t)n * RH * RW * a.ocs + a.ocoff;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int cy = min(row0 + r, a.H - 1), cx = min(gx, a.W - 1);
+    const unsigned off = (unsigned)(((cy >> a.res_up) * RW + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
+    rr[r][0] = resN[off];
+    rr[r][1] = resN[off + 1];
+  }
+}
+
+// accumulators start at bias + residual, so the epilogue is convert + store
+template <int R>
+__device__ __forceinline__ void conv_seed(f32x16_t (&acc)[R], const float4 (&b4)[4], const uint4 (&rr)[R][2], bool has_res) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
+    }
+    if (has_res) {
+      const unsigned rw[8] = {rr[r][0].x, rr[r][0].y, rr[r][0].z, rr[r][0].w, rr[r][1].x, rr[r][1].y, rr[r][1].z, rr[r][1].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
+        acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
+      }
+    }
+  }
+}
+
+// The implicit GEMM of one pass.  A pixel fragment (input row ir, column offset dx, k-step kc) serves the up to three
+// output rows r = ir - dy it is a tap of, so it is read from LDS once: (R+2)*3*KC ds_read_b128 for 9*KC*R MFMAs.  The
+// reads run DEPTH fragments ahead of their MFMAs through a register ring; the sched_barrier keeps the compiler from
+// hoisting them further (it would spill the resident weights: register budget in ConvCfg / DmaCfg).
+template <int R, int KC, int DEPTH, int PLANE, int LW>
+__device__ __forceinline__ void conv_mfma(const bf16x8_t* L, const bf16x8_t (&wfrag)[9 * KC], f32x16_t (&acc)[R]) {
+  constexpr int NF = (R + 2) * 3 * KC;
+  bf16x8_t ring[DEPTH];
+  auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
+#pragma unroll
+  for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
+  static_for<NF>([&](auto fc) {
+    constexpr int f = decltype(fc)::value;
+    if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
+    constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
+    static_for<3>([&](auto dc) {
+      constexpr int dy = decltype(dc)::value, r = ir - dy;
+      if constexpr (r >= 0 && r < R)
+        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// epilogue: fp32 -> bf16, 32 contiguous bytes per lane and row
+template <int R>
+__device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int row0, int gx, int c0, const f32x16_t (&acc)[R]) {
+  if (gx >= a.W) return;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int gy = row0 + r;
+    if (gy >= a.H) continue;
+    uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
+    op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
+                       cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
+    op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
+                       cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
+  }
+}
+
 template <int CIN, int COUT>
 struct ConvCfg {
   static constexpr int KC = CIN / 16;    // MFMA k-steps per tap
@@ -164,17 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     const int c0 = cb * 32 + hh * 16;
     // (pass 0 before the prologue, pass p+1 while pass p is on the matrix cores: one pass worth of registers)
     uint4 rr[R][2];
-    auto load_res = [&](int pass) {  // clamped: rows / columns past the image edge are never stored
-      const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
-      const uint4* resN = a.res + (size_t)n * RH * RW * a.ocs + a.ocoff;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int cy = min(y0 + (rg * PASSES + pass) * R + r, a.H - 1), cx = min(gx, a.W - 1);
-        const unsigned off = (unsigned)(((cy >> a.res_up) * RW + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
-        rr[r][0] = resN[off];
-        rr[r][1] = resN[off + 1];
-      }
-    };
+    auto load_res = [&](int pass) { conv_load_res<R>(a, n, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
     if (a.res) load_res(0);
     CONV_STAMP(1);
     __syncthreads();  // every wave is done reading the previous tile's planes
@@ -223,63 +293,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) b4[q] = bp[q];
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
-          }
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        if (a.res) {
-          const uint4 r0 = rr[r][0], r1 = rr[r][1];
-          const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
-            acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
-          }
-        }
+        conv_seed<R>(acc, b4, rr, a.res != nullptr);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (pass + 1 < PASSES && a.res) load_res(pass + 1);
       __builtin_amdgcn_sched_barrier(0);
-      // ---- implicit GEMM.  A pixel fragment (input row ir, column offset dx, k-step kc) serves the up to three
-      // output rows r = ir - dy it is a tap of, so it is read from LDS once: (R+2)*3*KC ds_read_b128 for
-      // 9*KC*R MFMAs.  The reads run DEPTH fragments ahead of their MFMAs through a register ring; the
-      // sched_barrier keeps the compiler from hoisting them further (register budget, see ConvCfg).
-      const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px;
-      constexpr int NF = (R + 2) * 3 * KC, DEPTH = POOL ? cfg::DEPTH_POOL : cfg::DEPTH;
-      bf16x8_t ring[DEPTH];
-      auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
-#pragma unroll
-      for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
-      static_for<NF>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
-        constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
-        static_for<3>([&](auto dc) {
-          constexpr int dy = decltype(dc)::value, r = ir - dy;
-          if constexpr (r >= 0 && r < R)
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
+      conv_mfma<R, KC, (POOL ? cfg::DEPTH_POOL : cfg::DEPTH), PLANE, LW>(
+          reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px, wfrag, acc);
       if (pass == PASSES - 1) CONV_STAMP(5);
-      // ---- epilogue: bf16, 32 contiguous bytes per lane and row
-      if (gx < a.W) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int gy = y0 + rbase + r;
-          if (gy >= a.H) continue;
-          uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
-          op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
-                             cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
-          op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
-                             cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
-        }
-      }
+      conv_store<R>(a, n, y0 + rbase, gx, c0, acc);
       // ---- the next level's input, max_pool2d(OUT, 2, 2), straight from the accumulators: row pairs are in this
       // wave's registers, column pairs are neighbouring lanes (max commutes with the bf16 rounding)
       if constexpr (POOL) {
@@ -316,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 template <int CIN, int COUT, bool UP>
 struct DmaCfg {
   static constexpr int KC = CIN / 16, NPL = CIN / 8, NCB = COUT / 32;
-  // CIN = 128: the 288 weight VGPRs of a wave only fit the 512-register budget of ONE wave per SIMD; the DMA
-  // pipeline (next window in flight during the MFMA loop) is what keeps that single wave fed
+  // (a CIN = 128 instantiation — 288 weight VGPRs, one wave per SIMD, two row passes — was measured at the same
+  // ~760 TFLOP/s as two 64-channel K-slices and dropped; WAVES_PER_SIMD / PASSES keep the knobs it needed)
   static constexpr int WAVES_PER_SIMD = CIN >= 128 ? 1 : 2;
   static constexpr int R = CIN >= 64 ? 2 : 4;      // output rows per wave and pass
   static constexpr int PASSES = CIN >= 128 ? 2 : 1;  // row passes per tile (accumulators reused): a taller tile, less halo
@@ -412,17 +434,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       for (int q = 0; q < 4; ++q) b4[q] = bp[q];
     }
     uint4 rr[R][2];
-    auto load_res = [&](int pass) {
-      const int RH = a.H >> a.res_up, RWd = a.W >> a.res_up;
-      const uint4* resN = a.res + (size_t)n * RH * RWd * a.ocs + a.ocoff;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int cy = min(y0 + (rg * PASSES + pass) * R + r, a.H - 1), cx = min(gx, a.W - 1);
-        const unsigned off = (unsigned)(((cy >> a.res_up) * RWd + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
-        rr[r][0] = resN[off];
-        rr[r][1] = resN[off + 1];
-      }
-    };
+    auto load_res = [&](int pass) { conv_load_res<R>(a, n, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
     if (a.res) load_res(0);
     CONV_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
@@ -452,59 +464,16 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       const int rbase = (rg * PASSES + pass) * R;
-      // ---- seed the accumulators with bias + residual
       f32x16_t acc[R];
-  #pragma unroll
-      for (int r = 0; r < R; ++r) {
-  #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w;
-        }
-        if (a.res) {
-          const unsigned rw[8] = {rr[r][0].x, rr[r][0].y, rr[r][0].z, rr[r][0].w, rr[r][1].x, rr[r][1].y, rr[r][1].z, rr[r][1].w};
-  #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            acc[r][2 * q] += cv_bf2f(rw[q] & 0xffffu);
-            acc[r][2 * q + 1] += cv_bf2f(rw[q] >> 16);
-          }
-        }
-      }
+      conv_seed<R>(acc, b4, rr, a.res != nullptr);
       __builtin_amdgcn_sched_barrier(0);
       if (pass == 0 && tile + nslots < t_end) issue_dma(tile + nslots);  // R is free: everyone passed the barrier after the prologue
       if (pass + 1 < PASSES && a.res) load_res(pass + 1);                   // consumed after this pass's MFMA loop
       __builtin_amdgcn_sched_barrier(0);
       if (pass == 0) CONV_STAMP(4);
-      // ---- implicit GEMM (as in k_conv3x3)
-      const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px;
-      constexpr int NF = (R + 2) * 3 * KC, DEPTH = cfg::DEPTH;
-      bf16x8_t ring[DEPTH];
-      auto frag = [&](int f) { return L[2 * (f % KC) * PLANE + (f / (3 * KC)) * LW + (f / KC) % 3]; };
-  #pragma unroll
-      for (int f = 0; f < DEPTH - 1; ++f) ring[f] = frag(f);
-      static_for<NF>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        if constexpr (f + DEPTH - 1 < NF) ring[(f + DEPTH - 1) % DEPTH] = frag(f + DEPTH - 1);
-        constexpr int ir = f / (3 * KC), dx = (f / KC) % 3, kc = f % KC;
-        static_for<3>([&](auto dc) {
-          constexpr int dy = decltype(dc)::value, r = ir - dy;
-          if constexpr (r >= 0 && r < R)
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[(dy * 3 + dx) * KC + kc], ring[f % DEPTH], acc[r], 0, 0, 0);
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
+      conv_mfma<R, KC, cfg::DEPTH, PLANE, LW>(reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px, wfrag, acc);
       if (pass == PASSES - 1) CONV_STAMP(5);
-      if (gx < a.W) {
-  #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int gy = y0 + rbase + r;
-          if (gy >= a.H) continue;
-          uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
-          op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
-                             cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
-          op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
-                             cv_pack2(acc[r][12], acc[r][13]), cv_pack2(acc[r][14], acc[r][15]));
-        }
-      }
+      conv_store<R>(a, n, y0 + rbase, gx, c0, acc);
     }
     CONV_STAMP(6);
   }
@@ -623,7 +592,6 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   if (CIN == 64 && COUT == 64 && !in_up) return launch_conv<64, 64, false>(ctx, a, stream);
   if (CIN == 64 && COUT == 64 && in_up) return launch_conv<64, 64, true>(ctx, a, stream);
   if (CIN == 64 && COUT == 128) return in_up ? launch_conv<64, 128, true>(ctx, a, stream) : launch_conv<64, 128, false>(ctx, a, stream);
-  if (CIN == 128 && COUT == 128 && !a.pool) return in_up ? launch_conv_dma<128, 128, true>(ctx, a, stream) : launch_conv_dma<128, 128, false>(ctx, a, stream);
   if (CIN == 32 && COUT == 64 && !in_up) return launch_conv<32, 64, false>(ctx, a, stream);
   aliby_set_error("conv3x3: unsupported (CIN=%d, COUT=%d, upsample=%d) combination", CIN, COUT, in_up);
   return ALIBY_ERR_UNSUPPORTED;

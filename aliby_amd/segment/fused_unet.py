@@ -66,8 +66,6 @@ class _Proj:
 
 # (CIN, COUT, input read through the 2x upsample) instantiations of k_conv3x3
 _MFMA_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 32, True), (64, 64, True), (64, 128, False), (64, 128, True)}
-# (the library also instantiates (128, 128, *) — one wave per SIMD with 288 weight registers — which measured no faster
-# than two 64-channel K-slices and is not used here)
 _POOL_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 128, False)}
 
 

@@ -159,8 +159,8 @@ int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* 
  * through RES.  OUT / RES / pool_out may likewise be the channel slice [out_channel0, out_channel0 + COUT) of
  * tensors with out_channels channels (0 = exactly COUT): wide outputs are produced slice by slice.  pool_out, when not NULL, also receives max_pool2d(OUT, 2, 2) as bf16 NHWC [N,H/2,W/2,COUT]
  * (cellpose's `downsample` maxpool, fused into the epilogue of the block's last convolution).
- * Supported (CIN, COUT, in_up): (32,32,0) (32,64,0) (64,64,0) (64,32,1) (64,64,1) (64,128,0) (64,128,1) (128,128,0)
- * (128,128,1; the last two without pool_out); anything else returns ALIBY_ERR_UNSUPPORTED. */
+ * Supported (CIN, COUT, in_up): (32,32,0) (32,64,0) (64,64,0) (64,32,1) (64,64,1) (64,128,0) (64,128,1);
+ * anything else returns ALIBY_ERR_UNSUPPORTED (wider layers: K/N slices, see above). */
 int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                           const float* shift, int shift_per_sample, const float* bias, const void* res,
                           int res_up, int N, int H, int W, int CIN, int COUT, int in_up, int in_channels,
