@@ -74,6 +74,8 @@ _SIGNATURES = {
     "aliby_track_stitch": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "aliby_debug_conv_trace": (_i, [_vp, _vp]),
     "aliby_nn_pack_conv3x3_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_nn_pack_conv1x1_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_nn_conv3x3_proj_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "aliby_nn_out_head_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "aliby_nn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "aliby_nn_tiles_to_nhwc8_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -79,6 +79,9 @@ struct ConvArgs {
   int ocs, ocoff;      // the same for OUT / RES / POOL (an output-channel slice of a wider tensor)
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
+  const uint4* pin;    // fused 1x1 projection: raw input [N, H, W, pcs*8] bf16 (NULL: none)
+  const uint4* pwpk;   // its packed weights ([cout block][k-step][lane]); the projection's bias rides in `bias`
+  int pcs;             // 16-byte units per projection input pixel
   unsigned long long* trace;  // diagnostics: per-phase shader-clock stamps of workgroup 0 (NULL in production)
 };
 
@@ -193,9 +196,13 @@ struct ConvCfg {
   static constexpr int DEPTH_POOL = (CIN >= 64 && COUT >= 64) ? 3 : 6;  // the pooling epilogue needs a few registers more
 };
 
-template <int CIN, int COUT, bool UP, bool POOL>
+// PK > 0: the residual block's 1x1 projection of the block input (cellpose `resdown.proj`, BatchNorm folded into its
+// weights) is PK extra k-steps of the same accumulation: its raw input tile (no halo, no activation) is staged beside
+// the window and the projected tensor never exists in HBM.
+template <int CIN, int COUT, bool UP, bool POOL, int PK>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   using cfg = ConvCfg<CIN, COUT>;
+  constexpr int PPLANE = (cfg::TH * cfg::TW) | 1;  // slot pitch of a projection-input octet plane
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
   constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, PASSES = cfg::PASSES;
   constexpr int PIX_PER_IT = cfg::PIX_PER_IT, ITERS = cfg::ITERS, BATCH = cfg::BATCH;
@@ -212,6 +219,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 9 * KC; ++i) wfrag[i] = wp[i * 64];
   }
+  bf16x8_t pfrag[PK > 0 ? PK : 1];
+  if constexpr (PK > 0) {
+    const bf16x8_t* pp = reinterpret_cast<const bf16x8_t*>(a.pwpk) + (size_t)cb * PK * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < PK; ++i) pfrag[i] = pp[i * 64];
+  }
+  uint4* const ldsP = lds + NPL * PLANE;
   // ---- staging role of this thread: a fixed channel octet
   const int pl = tid % NPL, pix0 = tid / NPL;
   const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;  // window coordinates of this thread's first pixel
@@ -278,6 +292,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         lds[pl * PLANE + p0 + (it0 + u) * PIX_PER_IT] = o;
       }
     }
+    if constexpr (PK > 0) {  // the projection's raw input tile: TH x TW pixels, 2*PK channel octets, no halo
+      constexpr int POCT = 2 * PK, PUNITS = TH * TW * POCT;
+      const uint4* pN = a.pin + (size_t)n * a.H * a.W * a.pcs;
+#pragma unroll
+      for (int it = 0; it < (PUNITS + 255) / 256; ++it) {
+        const int u = tid + it * 256;
+        if (u >= PUNITS) break;
+        const int oct = u % POCT, pix = u / POCT;
+        const int cy = min(y0 + pix / TW, a.H - 1), cx = min(x0 + pix % TW, a.W - 1);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (oct < a.pcs) v = pN[(unsigned)((cy * a.W + cx) * a.pcs + oct)];  // channels past the tensor's are zero
+        ldsP[oct * PPLANE + pix] = v;
+      }
+    }
     CONV_STAMP(3);
     __syncthreads();
     CONV_STAMP(4);
@@ -300,6 +328,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       conv_mfma<R, KC, (POOL ? cfg::DEPTH_POOL : cfg::DEPTH), PLANE, LW>(
           reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px, wfrag, acc);
+      if constexpr (PK > 0) {
+        const bf16x8_t* LP = reinterpret_cast<const bf16x8_t*>(ldsP) + hh * PPLANE + rbase * TW + px;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int k = 0; k < PK; ++k)
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfrag[k], LP[2 * k * PPLANE + r * TW], acc[r], 0, 0, 0);
+      }
       if (pass == PASSES - 1) CONV_STAMP(5);
       conv_store<R>(a, n, y0 + rbase, gx, c0, acc);
       // ---- the next level's input, max_pool2d(OUT, 2, 2), straight from the accumulators: row pairs are in this
@@ -482,7 +518,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
 // Packed layout: [cout block cb][tap][k-step kc][lane][8 bf16]; lane l holds the MFMA A fragment
 // A[row m = l&31][k = 8*(l>>5) + j] = W[cb*32 + chan(m)][cin = 16*kc + 8*(l>>5) + j][tap], with
 // chan(m) = 16*((m>>2)&1) + (m&3) + 4*(m>>3) (see the header comment).
-__global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, unsigned short* out, size_t total) {
+__global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, int taps, unsigned short* out, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
@@ -490,12 +526,12 @@ __global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, u
   const int kcn = cin / 16;
   const int kc = (int)(rest % kcn);
   rest /= kcn;
-  const int tap = (int)(rest % 9), cb = (int)(rest / 9);
+  const int tap = (int)(rest % taps), cb = (int)(rest / taps);
   const int m = lane & 31, h = lane >> 5;
   const int co = cb * 32 + 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
   const int ci = 16 * kc + 8 * h + j;
   float v = 0.f;
-  if (ci < cin_src && co < cout) v = w[((size_t)co * cin_src + ci) * 9 + tap];
+  if (ci < cin_src && co < cout) v = w[((size_t)co * cin_src + ci) * taps + tap];
   out[i] = (unsigned short)cv_f2bf(v);
 }
 
@@ -528,7 +564,7 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
   // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
   static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
-  if (use_dma && !a.pool) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
+  if (use_dma && !a.pool && !a.pin) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
   using cfg = ConvCfg<CIN, COUT>;
   a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
   a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
@@ -536,28 +572,44 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   ARG_CHECK(nt < INT_MAX, "conv3x3: too many tiles");
   a.ntiles = (int)nt;
   static bool attr_done = false;
+  constexpr int PKV = (!UP && CIN == 32 && COUT == 32) ? 1 : ((!UP && CIN == 64 && COUT == 64) ? 2 : 0);  // projection input: 16 / 32 channels
+  constexpr int P_BYTES = PKV ? 2 * PKV * ((cfg::TH * cfg::TW) | 1) * 16 : 0;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
+    if constexpr (PKV > 0)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, PKV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES + P_BYTES));
     attr_done = true;
   }
   const int per_xcd = (a.ntiles + 7) / 8;
   const int nslots = per_xcd < 64 ? per_xcd : 64;  // 2 workgroups per CU, 32 CUs per XCD
-  if (a.pool) hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
-  else hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  if (a.pin) {
+    if constexpr (PKV > 0) {
+      ARG_CHECK(!a.pool && a.pcs >= 1 && a.pcs <= 2 * PKV, "conv3x3: fused projection: unsupported input width");
+      hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, PKV>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES + P_BYTES, stream, a);
+    } else {
+      aliby_set_error("conv3x3: fused projection is built for (32,32) and (64,64) without upsampling only");
+      return ALIBY_ERR_UNSUPPORTED;
+    }
+  } else if (a.pool) {
+    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true, 0>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  } else {
+    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, 0>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  }
   KERNEL_CHECK();
   return ALIBY_OK;
 }
 
 }  // namespace
 
-extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
-                                     const float* shift, int shift_per_sample, const float* bias, const void* res,
-                                     int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
-                                     int in_channels, int in_channel0, int out_channels, int out_channel0,
-                                     void* pool_out, void* stream_) {
+static int conv3x3_entry(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                         const float* shift, int shift_per_sample, const float* bias, const void* res,
+                         int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
+                         int in_channels, int in_channel0, int out_channels, int out_channel0,
+                         void* pool_out, const void* proj_in, const void* proj_wpk, int proj_channels, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3: null argument");
   ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3: empty shape");
@@ -584,6 +636,10 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   a.ocs = out_channels / 8;
   a.ocoff = out_channel0 / 8;
   a.trace = g_conv_trace;
+  a.pin = static_cast<const uint4*>(proj_in);
+  a.pwpk = static_cast<const uint4*>(proj_wpk);
+  a.pcs = proj_channels / 8;
+  ARG_CHECK(!proj_in || (proj_wpk && proj_channels > 0 && proj_channels % 8 == 0), "conv3x3: fused projection needs packed weights and an octet-aligned width");
   a.cs = in_channels / 8;
   a.coff = in_channel0 / 8;
   a.N = N; a.H = H; a.W = W;
@@ -597,20 +653,45 @@ extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void*
   return ALIBY_ERR_UNSUPPORTED;
 }
 
+extern "C" int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                                     const float* shift, int shift_per_sample, const float* bias, const void* res,
+                                     int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
+                                     int in_channels, int in_channel0, int out_channels, int out_channel0,
+                                     void* pool_out, void* stream) {
+  return conv3x3_entry(ctx, in, wpk, out, scale, shift, shift_per_sample, bias, res, res_up, N, H, W, CIN, COUT, in_up, in_channels,
+                       in_channel0, out_channels, out_channel0, pool_out, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int aliby_nn_conv3x3_proj_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                                          const float* shift, int shift_per_sample, const float* bias, int N, int H, int W,
+                                          int CIN, int COUT, const void* proj_in, const void* proj_wpk, int proj_channels,
+                                          void* stream) {
+  ARG_CHECK(proj_in && proj_wpk, "conv3x3_proj: NULL projection operand");
+  return conv3x3_entry(ctx, in, wpk, out, scale, shift, shift_per_sample, bias, nullptr, 0, N, H, W, CIN, COUT, 0, 0, 0, 0, 0, nullptr,
+                       proj_in, proj_wpk, proj_channels, stream);
+}
+
 extern "C" int aliby_debug_conv_trace(aliby_ctx* ctx, void* stamps_dev) {
   ARG_CHECK(ctx != nullptr, "ctx is NULL");
   g_conv_trace = static_cast<unsigned long long*>(stamps_dev);
   return ALIBY_OK;
 }
 
-extern "C" int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN,
-                                          void* wpk, void* stream_) {
+static int pack_entry(aliby_ctx* ctx, const float* w, int COUT, int CIN_src, int CIN, int taps, void* wpk, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  ARG_CHECK(ctx && w_oihw && wpk, "pack_conv3x3: null argument");
-  ARG_CHECK(COUT > 0 && COUT % 32 == 0 && CIN % 16 == 0 && CIN_src > 0 && CIN_src <= CIN, "pack_conv3x3: COUT must be a multiple of 32 and CIN of 16");
-  const size_t total = (size_t)COUT * CIN * 9;
-  hipLaunchKernelGGL(k_pack_conv3x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w_oihw, COUT,
-                     CIN_src, CIN, static_cast<unsigned short*>(wpk), total);
+  ARG_CHECK(ctx && w && wpk, "pack_conv: null argument");
+  ARG_CHECK(COUT > 0 && COUT % 32 == 0 && CIN % 16 == 0 && CIN_src > 0 && CIN_src <= CIN, "pack_conv: COUT must be a multiple of 32 and CIN of 16");
+  const size_t total = (size_t)COUT * CIN * taps;
+  hipLaunchKernelGGL(k_pack_conv3x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, COUT, CIN_src, CIN, taps,
+                     static_cast<unsigned short*>(wpk), total);
   KERNEL_CHECK();
   return ALIBY_OK;
+}
+
+extern "C" int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk, void* stream) {
+  return pack_entry(ctx, w_oihw, COUT, CIN_src, CIN, 9, wpk, stream);
+}
+
+extern "C" int aliby_nn_pack_conv1x1_bf16(aliby_ctx* ctx, const float* w_oi, int COUT, int CIN_src, int CIN, void* wpk, void* stream) {
+  return pack_entry(ctx, w_oi, COUT, CIN_src, CIN, 1, wpk, stream);
 }

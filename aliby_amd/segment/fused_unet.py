@@ -4,7 +4,8 @@ Fused inference executor for the residual U-Net (aliby_amd/segment/unet.py).
 Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
   * the two high-resolution levels (32 / 64 channels, 75 % of the activation bytes) run on the hand-written
     MFMA convolution unit `k_conv3x3` (aliby_amd/csrc/nn_conv.hip): BatchNorm + ReLU + style shift in the
-    prologue, bias + residual / skip add in the epilogue, so a conv unit is ONE pass over HBM;
+    prologue, bias + residual / skip add (+ the block's 1x1 projection, + the 2x2 max pool) in the epilogue, so a
+    conv unit is ONE pass over HBM;
   * the deep levels (128 / 256 channels, compute-bound) keep torch.nn.functional.conv2d on bf16
     channels_last tensors (MIOpen / CK implicit GEMM), and there every pointwise stage between two
     convolutions (BatchNorm affine, ReLU, residual add, style add, nearest 2x upsampling) is ONE pass of
@@ -61,6 +62,8 @@ class _Proj:
         if pad_in is not None and w.shape[1] < pad_in:
             w = F.pad(w, (0, 0, 0, 0, 0, pad_in - w.shape[1]))
         self.w = w.to(dtype).contiguous(memory_format=CL)
+        self.w32 = w[:, :, 0, 0].contiguous()  # [O, I] fp32, BatchNorm folded: packed for the fused projection on demand
+        self.wpk = None
         self.bias = b.contiguous()
 
 
@@ -164,6 +167,36 @@ class FusedUNet:
                 cur, cur_up = out, False
         return (out, pooled) if pool else out
 
+    def _unit_proj(self, x, unit, shift, bias, x_in, proj):
+        """conv3x3(relu(scale*x + shift)) + bias + proj(x_in) in ONE launch (aliby_nn_conv3x3_proj_bf16): the residual
+        block's 1x1 projection of its raw input is a few extra k-steps, its output never touches HBM."""
+        n, cin, H, W = x.shape
+        cout = unit.w32.shape[0]
+        pc_pad = 16 if cin == 32 else 32
+        if unit.wpk is None:
+            unit.wpk = {}
+        key = (0, cin, 0, cout)
+        if key not in unit.wpk:
+            pk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(unit.w32), cout, cin, cin, _ptr(pk), _stream_ptr()))
+            unit.wpk[key] = pk
+        if proj.wpk is None:
+            proj.wpk = torch.empty(cout * pc_pad, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv1x1_bf16(self.h, _ptr(proj.w32), cout, proj.w32.shape[1], pc_pad, _ptr(proj.wpk), _stream_ptr()))
+        sh = unit.shift if shift is None else shift
+        out = self._new(n, cout, H, W)
+        group = "conv3x3_mfma"
+        timer = self.eng.timed(group)
+        if timer.active:
+            st = self.conv_stats.setdefault(group, [0, 0])
+            st[0] += 2 * (x.numel() + out.numel() + x_in.numel())
+            st[1] += 2 * (9 * cin + x_in.shape[1]) * cout * n * H * W
+        with timer:
+            _lib.check(self.lib.aliby_nn_conv3x3_proj_bf16(
+                self.h, _ptr(x), _ptr(unit.wpk[key]), _ptr(out), _ptr(unit.scale), _ptr(sh), self._sps(sh), _ptr(bias), n, H, W, cin, cout,
+                _ptr(x_in), _ptr(proj.wpk), x_in.shape[1], _stream_ptr()))
+        return out
+
     def _launch_unit(self, x, unit, kslice, nslice, out, shift, bias, res, res_up, in_up, pooled):
         n, ctot, cout_tot = x.shape[0], x.shape[1], out.shape[1]
         (k0, k1), (n0, n1) = kslice, nslice
@@ -209,13 +242,18 @@ class FusedUNet:
     def _down_mfma(self, i, d, x_raw, x_act):
         """Residual down block on the MFMA unit: 4 launches, no pointwise passes."""
         u = d["u"]
-        p = self._conv(x_raw, d["proj"], pad=0)
+        fuse_proj = (u[1].w32.shape[1], u[1].w32.shape[0]) in ((32, 32), (64, 64))  # projection rides in conv1's launch
+        p = None if fuse_proj else self._conv(x_raw, d["proj"], pad=0)
         if i == 0:  # 2 -> 32 channels: K = 18 is too thin for the unit; CK conv, its bias rides in the next shift
             c0 = self._conv(x_act, u[0])
-            x1 = self._unit(c0, u[1], shift=d["shift1_b0"], bias=d["pb1"], res=p)
+            sh1 = d["shift1_b0"]
         else:
             c0 = self._unit(x_raw, u[0], bias=u[0].bias)
-            x1 = self._unit(c0, u[1], bias=d["pb1"], res=p)
+            sh1 = None
+        if fuse_proj:
+            x1 = self._unit_proj(c0, u[1], sh1, d["pb1"], x_raw, d["proj"])
+        else:
+            x1 = self._unit(c0, u[1], shift=sh1, bias=d["pb1"], res=p)
         c2 = self._unit(x1, u[2], bias=u[2].bias)
         return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=i + 1 < len(self.down) and u[3].w32.shape[0] <= 128)  # (x2, maxpool(x2))
 

@@ -185,9 +185,21 @@ int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const uint16_t* cur
  * (uint64: 0 tile start, 1 loads issued, 2 after barrier, 3 prologue done, 4 after barrier, 5 MFMA done,
  * 6 stores issued).  NULL switches it off (the default). */
 int aliby_debug_conv_trace(aliby_ctx* ctx, void* stamps_dev);
+/* The same unit with the residual block's 1x1 projection fused in (cellpose `resdown`: x = proj(x_in) + conv1(conv0(x_in))):
+ *   OUT = conv3x3( relu(scale*IN + shift) ) + bias + proj_w . PROJ_IN[n,y,x,:]
+ * PROJ_IN is the block's RAW input [N,H,W,proj_channels] bf16 (no activation; the projection's BatchNorm is folded into
+ * proj_w, its bias into `bias`), so the projected tensor never exists in HBM.  proj_wpk comes from
+ * aliby_nn_pack_conv1x1_bf16 with CIN = 16 (for (CIN,COUT) = (32,32), proj_channels <= 16) or 32 ((64,64), <= 32). */
+int aliby_nn_conv3x3_proj_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                               const float* shift, int shift_per_sample, const float* bias, int N, int H, int W,
+                               int CIN, int COUT, const void* proj_in, const void* proj_wpk, int proj_channels,
+                               void* stream);
 /* float32 OIHW [COUT, CIN_src, 3, 3] device weights -> the MFMA fragment order the kernel above reads
  * ([COUT/32][9 taps][CIN/16][64 lanes][8] bf16, COUT*CIN*9*2 bytes; input channels >= CIN_src are zero). */
 int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk,
+                               void* stream);
+/* float32 [COUT, CIN_src] device weights of a 1x1 convolution -> [COUT/32][CIN/16][64 lanes][8] bf16 (same row order). */
+int aliby_nn_pack_conv1x1_bf16(aliby_ctx* ctx, const float* w_oi, int COUT, int CIN_src, int CIN, void* wpk,
                                void* stream);
 /* network output bf16 NHWC [N,H,W,Cpad] (+ bias[Cout]) -> float32 NCHW [N,Cout,H,W]. */
 int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W, int Cpad, int Cout,

@@ -162,6 +162,39 @@ def test_conv_unit_n_split_into_output_channel_slices(engine):
     assert torch.equal(out.float(), ref)
 
 
+@pytest.mark.parametrize("cin,pc", [(32, 8), (32, 16), (64, 32)])
+def test_conv_unit_with_fused_projection(engine, cin, pc):
+    """conv3x3(relu(scale*x + shift)) + bias + conv1x1(x_in) in one launch: the residual block's projection rides in the
+    accumulation (exact on integer data)."""
+    import torch
+    import torch.nn.functional as F
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    g = torch.Generator().manual_seed(cin + pc)
+    n, H, W, cout = 2, 37, 45, cin
+    x = torch.randint(-1, 3, (n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
+    xin = torch.randint(-2, 3, (n, H, W, pc), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
+    wp = torch.randint(-1, 2, (cout, pc), generator=g).float().cuda()
+    scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (cin,), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
+    pc_pad = 16 if cin == 32 else 32
+    wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+    ppk = torch.empty(cout * pc_pad, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), cout, cin, cin, _ptr(wpk), _stream_ptr()))
+    _lib.check(engine.lib.aliby_nn_pack_conv1x1_bf16(engine.ctx.handle, _ptr(wp), cout, pc, pc_pad, _ptr(ppk), _stream_ptr()))
+    out = torch.full((n, H, W, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_conv3x3_proj_bf16(engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 0,
+                                                     _ptr(bias), n, H, W, cin, cout, _ptr(xin), _ptr(ppk), pc, _stream_ptr()))
+    torch.cuda.synchronize()
+    ref = _reference(x, w, scale, shift, bias, None, False, False)
+    ref = ref + F.conv2d(xin.float().permute(0, 3, 1, 2), wp[:, :, None, None]).permute(0, 2, 3, 1)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(out.float(), ref)
+
+
 def test_conv_unit_rejects_unsupported_shapes(engine):
     import torch
     from aliby_amd import _lib
