@@ -2,17 +2,15 @@
 Fused inference executor for the residual U-Net (aliby_amd/segment/unet.py).
 
 Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
-  * the two high-resolution levels (32 / 64 channels, 75 % of the activation bytes) run on the hand-written
-    MFMA convolution unit `k_conv3x3` (aliby_amd/csrc/nn_conv.hip): BatchNorm + ReLU + style shift in the
-    prologue, bias + residual / skip add (+ the block's 1x1 projection, + the 2x2 max pool) in the epilogue, so a
-    conv unit is ONE pass over HBM;
-  * the deep levels (128 / 256 channels, compute-bound) keep torch.nn.functional.conv2d on bf16
-    channels_last tensors (MIOpen / CK implicit GEMM), and there every pointwise stage between two
-    convolutions (BatchNorm affine, ReLU, residual add, style add, nearest 2x upsampling) is ONE pass of
-    the hand-written `k_fused_act` kernel (aliby_amd/csrc/nn_fused.hip) instead of 2-4 eager passes;
-  * BatchNorm in front of the 1x1 projections is folded into their weights; projections of the up path
-    run at the low resolution and are read through the upsample (a 1x1 conv commutes with nearest
-    upsampling).
+  * every 3x3 convolution unit of all four levels runs on the hand-written MFMA convolution unit `k_conv3x3`
+    (aliby_amd/csrc/nn_conv.hip): BatchNorm + ReLU + style shift in the prologue, bias + residual / skip add (+ the
+    block's 1x1 projection at levels 0-1, + the 2x2 max pool) in the epilogue, so a conv unit is ONE pass over HBM;
+    layers wider than one launch holds (128 / 256 channels) are split along K and N (`mfma_levels` selects the
+    levels; the others fall back to MIOpen convolutions with the fused pointwise kernel `k_fused_act` between them);
+  * the output head (BatchNorm + ReLU + 1x1 conv + NHWC->NCHW) is one kernel (`k_out_head`);
+  * what is left to the library: the 2-channel first convolution, the 1x1 projections of the deep / up blocks
+    (BatchNorm folded into their weights; the up path's run at the low resolution and are read through the upsample:
+    a 1x1 conv commutes with nearest upsampling) and the style vector's tiny reductions / one batched GEMM.
 """
 
 from __future__ import annotations
