@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void k_follow(const float* __restrict__ im, co
     const int y = (int)(p / W), x = (int)(p % W);
     float px = (float)x / sx * 2.0f - 1.0f;
     float py = (float)y / sy * 2.0f - 1.0f;
+    // The eight taps of the bilinear sample are kept in registers and re-read only when the point enters another
+    // pixel cell: points reach their sink within a few dozen steps and then jitter inside one cell, so most of the
+    // 200 steps issue no loads at all (the kernel is bound by the gather address rate otherwise).
+    int cell_x = INT_MIN, cell_y = INT_MIN;
+    float xnw = 0.f, xne = 0.f, xsw = 0.f, xse = 0.f, ynw = 0.f, yne = 0.f, ysw = 0.f, yse = 0.f;
     for (int t = 0; t < niter; ++t) {
       const float ix = ((px + 1.0f) * Wf - 1.0f) / 2.0f;
       const float iy = ((py + 1.0f) * Hf - 1.0f) / 2.0f;
@@ -110,15 +115,21 @@ __global__ __launch_bounds__(256) void k_follow(const float* __restrict__ im, co
       const float wne = (ix - x0) * (y1 - iy);
       const float wsw = (x1 - ix) * (iy - y0);
       const float wse = (ix - x0) * (iy - y0);
-      const int x0i = (int)x0, y0i = (int)y0, x1i = (int)x1, y1i = (int)y1;
-      float dx = 0.0f + tap(imx, y0i, x0i, H, W) * wnw;
-      dx = dx + tap(imx, y0i, x1i, H, W) * wne;
-      dx = dx + tap(imx, y1i, x0i, H, W) * wsw;
-      dx = dx + tap(imx, y1i, x1i, H, W) * wse;
-      float dy = 0.0f + tap(imy, y0i, x0i, H, W) * wnw;
-      dy = dy + tap(imy, y0i, x1i, H, W) * wne;
-      dy = dy + tap(imy, y1i, x0i, H, W) * wsw;
-      dy = dy + tap(imy, y1i, x1i, H, W) * wse;
+      const int x0i = (int)x0, y0i = (int)y0;
+      if (x0i != cell_x || y0i != cell_y) {
+        const int x1i = (int)x1, y1i = (int)y1;
+        xnw = tap(imx, y0i, x0i, H, W); xne = tap(imx, y0i, x1i, H, W); xsw = tap(imx, y1i, x0i, H, W); xse = tap(imx, y1i, x1i, H, W);
+        ynw = tap(imy, y0i, x0i, H, W); yne = tap(imy, y0i, x1i, H, W); ysw = tap(imy, y1i, x0i, H, W); yse = tap(imy, y1i, x1i, H, W);
+        cell_x = x0i; cell_y = y0i;
+      }
+      float dx = 0.0f + xnw * wnw;
+      dx = dx + xne * wne;
+      dx = dx + xsw * wsw;
+      dx = dx + xse * wse;
+      float dy = 0.0f + ynw * wnw;
+      dy = dy + yne * wne;
+      dy = dy + ysw * wsw;
+      dy = dy + yse * wse;
       px = fminf(fmaxf(px + dx, -1.0f), 1.0f);
       py = fminf(fmaxf(py + dy, -1.0f), 1.0f);
     }
