@@ -31,6 +31,23 @@ if files:
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             w.writerow([k, a[0], round(a[1] / 1e3, 1), round(a[1] / a[0] / 1e3, 2), round(a[2] / 1e3, 2), round(a[3] / 1e3, 2), round(100 * a[1] / tot, 2)])
     print("steady step: kernel time", tot / 1e6, "ms over", len(seg), "launches")
+    # the bench's timing groups, from the same trace: what `roofline.avg_launch_ms` / `roofline_mfma.avg_launch_ms` must agree with
+    def grp(k):
+        if k.startswith("k_conv3x3"):
+            return "conv3x3_mfma_deep" if ", 128," in k else "conv3x3_mfma"
+        if k.startswith("k_fused_act"):
+            return "fused_pointwise"
+        if k.startswith("k_out_head"):
+            return "out_head"
+        return None
+    groups_t = {}
+    for k, a in agg.items():
+        g = grp(k)
+        if g:
+            t = groups_t.setdefault(g, [0, 0])
+            t[0] += a[0]; t[1] += a[1]
+    json.dump({g: {"launches_per_step": t[0], "total_ms_per_step": round(t[1] / 1e6, 3), "avg_launch_ms": round(t[1] / t[0] / 1e6, 4)}
+               for g, t in groups_t.items()}, open(f"profiles/{tag}_group_avg_from_trace.json", "w"), indent=1)
 
 # ---- HBM traffic of the hand-written kernels from the PMC passes
 traffic = {}
