@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--fovs", type=int, default=32, help="FOVs per step per GPU")
+    ap.add_argument("--fovs", type=int, default=64, help="FOVs per step per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic FOVs generated per rank (replicated)")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--net-dtype", default="bfloat16", choices=["bfloat16", "float32", "float16"])
