@@ -8,9 +8,11 @@ Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
     layers wider than one launch holds (128 / 256 channels) are split along K and N (`mfma_levels` selects the
     levels; the others fall back to MIOpen convolutions with the fused pointwise kernel `k_fused_act` between them);
   * the output head (BatchNorm + ReLU + 1x1 conv + NHWC->NCHW) is one kernel (`k_out_head`);
-  * what is left to the library: the 2-channel first convolution, the 1x1 projections of the deep / up blocks
-    (BatchNorm folded into their weights; the up path's run at the low resolution and are read through the upsample:
-    a 1x1 conv commutes with nearest upsampling) and the style vector's tiny reductions / one batched GEMM.
+  * the 2-channel first layer (`k_first_conv`: im2col gathered from LDS into two MFMA k-steps) and the 1x1 projections of
+    the deep / up blocks (`k_conv1x1`; BatchNorm folded into their weights; the up path's run at the low resolution and
+    are read through the upsample: a 1x1 conv commutes with nearest upsampling) are hand-written too
+    (aliby_amd/csrc/nn_conv1x1.hip): no MIOpen / rocBLAS convolution is called;
+  * what is left to torch: the style vector (a spatial mean, a normalisation, one batched [N,256] x [256,1440] GEMM).
 """
 
 from __future__ import annotations
@@ -61,7 +63,8 @@ class _Proj:
             w = F.pad(w, (0, 0, 0, 0, 0, pad_in - w.shape[1]))
         self.w = w.to(dtype).contiguous(memory_format=CL)
         self.w32 = w[:, :, 0, 0].contiguous()  # [O, I] fp32, BatchNorm folded: packed for the fused projection on demand
-        self.wpk = None
+        self.wpk = None   # packed for the projection fused into conv1 (levels 0-1)
+        self.wpk1 = None  # packed for the standalone 1x1 kernel
         self.bias = b.contiguous()
 
 
@@ -105,6 +108,8 @@ class FusedUNet:
                 off += k.scale.numel()
         self.style_w = torch.cat(ws, dim=1).contiguous()  # [style, sum C]
         self.style_b = torch.cat(bs).contiguous()
+        # first layer's weights [32, cin, 3, 3], bf16-rounded like the convolution it replaces
+        self.first_w = net.down[0].conv[0][-1].weight.detach().float().to(dtype).float().contiguous()
         self.out = _Unit(net.output, dtype)
         self.out_w = self.out.w32[:, :, 0, 0].to(dtype).float().contiguous()  # [O, 32], bf16-rounded like the conv it replaces
         self.cin = net.nbase[0]
@@ -140,6 +145,21 @@ class FusedUNet:
     @staticmethod
     def _conv(x, unit, pad=1):
         return F.conv2d(x, unit.w, None, padding=pad)  # bias is applied by the next fused pass
+
+    def _proj(self, x, proj):
+        """1x1 projection (BatchNorm folded, bias added later by the consumer): hand-written MFMA GEMM for the widths
+        the kernel is built for, MIOpen otherwise."""
+        n, cin, H, W = x.shape
+        cout = proj.w32.shape[0]
+        if cin not in (32, 64, 128, 256) or not (cout in (32, 64) or cout % 128 == 0) or proj.w32.shape[1] != cin:
+            return self._conv(x, proj, pad=0)
+        if proj.wpk1 is None:
+            proj.wpk1 = torch.empty(cout * cin, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv1x1_bf16(self.h, _ptr(proj.w32), cout, cin, cin, _ptr(proj.wpk1), _stream_ptr()))
+        out = self._new(n, cout, H, W)
+        with self.eng.timed("conv1x1_mfma"):
+            _lib.check(self.lib.aliby_nn_conv1x1_bf16(self.h, _ptr(x), _ptr(proj.wpk1), 0, _ptr(out), n, H, W, cin, cout, _stream_ptr()))
+        return out
 
     def _unit(self, x, unit, shift=None, bias=None, res=None, res_up=False, in_up=False, pool=False):
         """conv3x3(relu(scale*x + shift)) + bias + res on the MFMA convolution unit.  One launch when the shape is
@@ -241,9 +261,9 @@ class FusedUNet:
         """Residual down block on the MFMA unit: 4 launches, no pointwise passes."""
         u = d["u"]
         fuse_proj = (u[1].w32.shape[1], u[1].w32.shape[0]) in ((32, 32), (64, 64))  # projection rides in conv1's launch
-        p = None if fuse_proj else self._conv(x_raw, d["proj"], pad=0)
-        if i == 0:  # 2 -> 32 channels: K = 18 is too thin for the unit; CK conv, its bias rides in the next shift
-            c0 = self._conv(x_act, u[0])
+        p = None if fuse_proj else self._proj(x_raw, d["proj"])
+        if i == 0:  # 2 -> 32 channels: K = 18 is too thin for the matrix cores; c0 comes from the first-layer kernel (or
+            c0 = x_act if self._first_c0 else self._conv(x_act, u[0])  # MIOpen), its bias rides in the next shift
             sh1 = d["shift1_b0"]
         else:
             c0 = self._unit(x_raw, u[0], bias=u[0].bias)
@@ -257,7 +277,7 @@ class FusedUNet:
 
     def _up_mfma(self, d, x, skip, style, up=True):
         u = d["u"]
-        p_low = self._conv(x, d["proj"], pad=0)  # 1x1 at the low resolution, read through the upsample as a residual
+        p_low = self._proj(x, d["proj"])  # 1x1 at the low resolution, read through the upsample as a residual
         c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=up)  # wider than one launch holds: split along K / N
         sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
         x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=up)
@@ -272,9 +292,16 @@ class FusedUNet:
         n, cin, H, W = tiles.shape
         d0 = self.down[0]
         raw = self._new(n, 8, H, W)
-        act = self._new(n, 8, H, W)
-        _lib.check(self.lib.aliby_nn_tiles_to_nhwc8_bf16(self.h, _ptr(tiles), n, cin, H, W, _ptr(d0["u"][0].scale),
-                                                         _ptr(d0["u"][0].shift), _ptr(raw), _ptr(act), _stream_ptr()))
+        self._first_c0 = 0 in self.mfma_levels and cin <= 2
+        if self._first_c0:  # first-layer kernel: `act` IS c0 = conv3x3(relu(bn(x))) (32 channels), no MIOpen call
+            act = self._new(n, 32, H, W)
+            with self.eng.timed("first_conv"):
+                _lib.check(self.lib.aliby_nn_first_conv_bf16(self.h, _ptr(tiles), n, cin, H, W, _ptr(d0["u"][0].scale), _ptr(d0["u"][0].shift),
+                                                             _ptr(self.first_w), _ptr(raw), _ptr(act), _stream_ptr()))
+        else:
+            act = self._new(n, 8, H, W)
+            _lib.check(self.lib.aliby_nn_tiles_to_nhwc8_bf16(self.h, _ptr(tiles), n, cin, H, W, _ptr(d0["u"][0].scale),
+                                                             _ptr(d0["u"][0].shift), _ptr(raw), _ptr(act), _stream_ptr()))
         feats, pooled = [], None
         x_raw, x_act = raw, act
         for i, d in enumerate(self.down):

@@ -204,6 +204,18 @@ int aliby_nn_pack_conv1x1_bf16(aliby_ctx* ctx, const float* w_oi, int COUT, int 
 /* network output bf16 NHWC [N,H,W,Cpad] (+ bias[Cout]) -> float32 NCHW [N,Cout,H,W]. */
 int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W, int Cpad, int Cout,
                               const float* bias, float* out, void* stream);
+/* 1x1 convolution of the network (cellpose `resdown.proj` / `resup.proj`: BatchNorm -> Conv2d(1x1), BatchNorm folded into
+ * the weights by the caller): OUT[n,y,x,:] = W . IN[n,y,x,:] + bias, bf16 NHWC, hand-written MFMA GEMM over the N*H*W
+ * pixels.  wpk from aliby_nn_pack_conv1x1_bf16(COUT, CIN, CIN).  CIN in {32, 64, 128, 256}; COUT 32, 64 or a multiple of
+ * 128; bias may be NULL. */
+int aliby_nn_conv1x1_bf16(aliby_ctx* ctx, const void* in, const void* wpk, const float* bias, void* out, int N, int H, int W,
+                          int CIN, int COUT, void* stream);
+/* First layer of the network on float32 NCHW tiles with Cin <= 2 channels (the 2-channel input cellpose builds):
+ * c0 = conv3x3(bf16(relu(scale[c]*x + shift[c])), zero padded) as bf16 NHWC[32] WITHOUT the convolution's bias, and the raw
+ * input as bf16 NHWC[8] (channels >= Cin zero) for the block's projection.  w_oihw: float32 [32, Cin, 3, 3] (pass bf16-
+ * representable values to reproduce a bf16 convolution). */
+int aliby_nn_first_conv_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W, const float* scale,
+                             const float* shift, const float* w_oihw, void* raw8, void* c0, void* stream);
 /* Output head of the network (cellpose CPnet.output = BatchNorm -> ReLU -> 1x1 Conv2d, the flows + cellprob
  * that `model.eval` (segment/dispatch.py:208-215) returns): x bf16 NHWC [N,H,W,32] -> float32 NCHW [N,O,H,W],
  * y = bias[o] + sum_c w[o,c] * bf16(relu(scale[c]*x + shift[c])); w is float32 [O,32] (bf16-representable values

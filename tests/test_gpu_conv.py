@@ -195,6 +195,56 @@ def test_conv_unit_with_fused_projection(engine, cin, pc):
     assert torch.equal(out.float(), ref)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 128), (128, 64), (128, 256), (256, 256), (256, 128)])
+def test_conv1x1_exact_on_integer_data(engine, cin, cout):
+    import torch
+    import torch.nn.functional as F
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    n, H, W = 3, 13, 21  # 819 pixels: not a multiple of the 128 / 64-pixel tile
+    x = torch.randint(-2, 3, (n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, cin), generator=g) * (torch.rand(cout, cin, generator=g) < 0.3)).float().cuda()
+    bias = torch.randint(-3, 4, (cout,), generator=g).float().cuda()
+    wpk = torch.empty(cout * cin, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv1x1_bf16(engine.ctx.handle, _ptr(w), cout, cin, cin, _ptr(wpk), _stream_ptr()))
+    out = torch.full((n, H, W, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_conv1x1_bf16(engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(bias), _ptr(out), n, H, W, cin, cout, _stream_ptr()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w[:, :, None, None], bias).permute(0, 2, 3, 1)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(out.float(), ref)
+
+
+@pytest.mark.parametrize("cin", [1, 2])
+def test_first_layer_kernel_matches_torch(engine, cin):
+    """float32 NCHW tiles -> c0 = conv3x3(bf16(relu(scale*x + shift))) (bf16 NHWC[32]) + the raw bf16 NHWC[8] copy."""
+    import torch
+    import torch.nn.functional as F
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    g = torch.Generator().manual_seed(40 + cin)
+    n, H, W = 2, 45, 70
+    x = torch.randn(n, cin, H, W, generator=g).cuda()
+    w = (torch.randn(32, cin, 3, 3, generator=g) * 0.3).bfloat16().float().cuda()
+    scale = torch.cat([torch.rand(cin, generator=g) + 0.5, torch.ones(8 - cin)]).cuda()
+    shift = torch.cat([torch.randn(cin, generator=g) * 0.2, torch.zeros(8 - cin)]).cuda()
+    raw = torch.full((n, H, W, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    c0 = torch.full((n, H, W, 32), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_first_conv_bf16(engine.ctx.handle, _ptr(x), n, cin, H, W, _ptr(scale), _ptr(shift), _ptr(w), _ptr(raw),
+                                                   _ptr(c0), _stream_ptr()))
+    torch.cuda.synchronize()
+    act = torch.relu(x * scale[None, :cin, None, None] + shift[None, :cin, None, None]).bfloat16().float()
+    ref = F.conv2d(act, w, None, padding=1).permute(0, 2, 3, 1)
+    err = (c0.float() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2.0**-7, float(err)
+    want_raw = torch.zeros(n, H, W, 8, device="cuda")
+    want_raw[..., :cin] = x.permute(0, 2, 3, 1).bfloat16().float()
+    assert torch.equal(raw.float(), want_raw)
+
+
 def test_conv_unit_rejects_unsupported_shapes(engine):
     import torch
     from aliby_amd import _lib
