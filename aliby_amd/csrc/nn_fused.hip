@@ -167,6 +167,63 @@ __global__ __launch_bounds__(256) void k_out_head(const bf16_t* __restrict__ x, 
   }
 }
 
+// style vector of the network and everything derived from it, one workgroup per sample:
+//   style[n, c]  = mean over (y, x) of X[n, y, x, c]            (cellpose `make_style`: global average pool ...
+//   style[n, :] /= sqrt(sum_c style[n, c]^2)                     ... L2-normalised)
+//   shifts[n, j] = b[j] + sum_c style[n, c] * Wt[c, j]            (the per-sample shifts of every styled unit of the up path:
+//                                                                 `batchconvstyle.full` folded with its BatchNorm, batched)
+__global__ __launch_bounds__(256) void k_style(const bf16_t* __restrict__ x, int P, int C, const float* __restrict__ wt,
+                                               const float* __restrict__ b, int J, float* __restrict__ style,
+                                               float* __restrict__ shifts) {
+  // grid (N, ceil(J/256)): every workgroup rebuilds the sample's style (the feature map is small and L2-resident) and
+  // produces its 256-wide slice of the shifts; workgroup (n, 0) also writes the style vector.
+  extern __shared__ float sv[];  // [C] style, then [groups][C] partial sums, then [8] reduction scratch
+  const int C8 = C >> 3, groups = blockDim.x / C8;  // C8 lanes cover a pixel (16-byte loads), `groups` pixels at a time
+  float* part = sv + C;
+  float* red = part + groups * C;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const bf16x8* xn = reinterpret_cast<const bf16x8*>(x) + (size_t)n * P * C8;
+  if (tid < groups * C8) {
+    const int c8 = tid % C8, g = tid / C8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = g; p < P; p += groups) {
+      const bf16x8 v = xn[(size_t)p * C8 + c8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += bf2f(v.v[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[g * C + c8 * 8 + k] = s[k];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += part[g * C + c];  // fixed order: deterministic
+    sv[c] = s / (float)P;
+  }
+  __syncthreads();
+  float q = 0.f;
+  for (int c = tid; c < C; c += blockDim.x) q += sv[c] * sv[c];
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_down(q, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+  const float inv = 1.0f / sqrtf(tot);
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    sv[c] *= inv;
+    if (blockIdx.y == 0) style[(size_t)n * C + c] = sv[c];
+  }
+  __syncthreads();
+  const int j = blockIdx.y * blockDim.x + tid;
+  if (j < J) {
+    float acc = b[j];
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) acc += sv[c] * wt[(size_t)c * J + j];
+    shifts[(size_t)n * J + j] = acc;
+  }
+}
+
 extern "C" {
 
 int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* SUM, void* ACT, const float* bias,
@@ -228,6 +285,18 @@ int aliby_nn_out_head_bf16(aliby_ctx* ctx, const void* x, const float* scale, co
   const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(k_out_head, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(x), scale, shift, w, bias, O, (size_t)N, P, out);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+int aliby_nn_style_bf16(aliby_ctx* ctx, const void* x, int N, int H, int W, int C, const float* wt, const float* b, int J,
+                        float* style, float* shifts, void* stream) {
+  ARG_CHECK(ctx && x && wt && b && style && shifts, "style: null argument");
+  ARG_CHECK(N > 0 && H > 0 && W > 0 && J > 0 && C >= 8 && C % 8 == 0 && C <= 2048, "style: C must be a multiple of 8, <= 2048");
+  const int groups = 256 / (C / 8) > 0 ? 256 / (C / 8) : 0;
+  ARG_CHECK(groups >= 1, "style: C too wide for one workgroup");
+  hipLaunchKernelGGL(k_style, dim3(N, (J + 255) / 256), dim3(256), sizeof(float) * ((size_t)C + (size_t)groups * C + 8), static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(x), H * W, C, wt, b, J, style, shifts);
   KERNEL_CHECK();
   return ALIBY_OK;
 }

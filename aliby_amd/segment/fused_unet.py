@@ -12,7 +12,8 @@ Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
     the deep / up blocks (`k_conv1x1`; BatchNorm folded into their weights; the up path's run at the low resolution and
     are read through the upsample: a 1x1 conv commutes with nearest upsampling) are hand-written too
     (aliby_amd/csrc/nn_conv1x1.hip): no MIOpen / rocBLAS convolution is called;
-  * what is left to torch: the style vector (a spatial mean, a normalisation, one batched [N,256] x [256,1440] GEMM).
+  * the style vector (spatial mean, L2 normalisation) and the per-sample shifts of all styled units derived from it are one
+    small kernel (`k_style`): torch computes nothing in the forward pass, it only owns the buffers.
 """
 
 from __future__ import annotations
@@ -327,9 +328,12 @@ class FusedUNet:
             c3 = self._conv(a3, u[3])
             x2, _ = self._fused(x1, c3, want_sum=True, bias=u[3].bias)
             feats.append(x2)
-        style = feats[-1].float().mean(dim=(2, 3))
-        style = style / torch.sum(style**2, dim=1, keepdim=True) ** 0.5
-        self._style_all = torch.addmm(self.style_b, style, self.style_w)  # [N, sum C]
+        deep = feats[-1]
+        style = torch.empty((n, deep.shape[1]), dtype=torch.float32, device="cuda")
+        self._style_all = torch.empty((n, self.style_b.numel()), dtype=torch.float32, device="cuda")  # [N, sum C]
+        with self.eng.timed("style"):
+            _lib.check(self.lib.aliby_nn_style_bf16(self.h, _ptr(deep), n, deep.shape[2], deep.shape[3], deep.shape[1], _ptr(self.style_w),
+                                                    _ptr(self.style_b), self.style_b.numel(), _ptr(style), _ptr(self._style_all), _stream_ptr()))
         x, up = feats[-1], False
         for i in range(len(self.up) - 1, -1, -1):
             d = self.up[i]

@@ -216,6 +216,12 @@ int aliby_nn_conv1x1_bf16(aliby_ctx* ctx, const void* in, const void* wpk, const
  * representable values to reproduce a bf16 convolution). */
 int aliby_nn_first_conv_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W, const float* scale,
                              const float* shift, const float* w_oihw, void* raw8, void* c0, void* stream);
+/* Style vector of the network (cellpose `make_style`: global average pool of the deepest feature map, L2-normalised) and
+ * the per-sample shifts of every styled unit derived from it in one batched product: x bf16 NHWC [N,H,W,C] ->
+ * style float32 [N,C]; shifts[n,:] = b + style[n,:] . wt, wt float32 [C,J] (`batchconvstyle.full` of all units, folded with
+ * their BatchNorm by the caller), shifts float32 [N,J]. */
+int aliby_nn_style_bf16(aliby_ctx* ctx, const void* x, int N, int H, int W, int C, const float* wt, const float* b, int J,
+                        float* style, float* shifts, void* stream);
 /* Output head of the network (cellpose CPnet.output = BatchNorm -> ReLU -> 1x1 Conv2d, the flows + cellprob
  * that `model.eval` (segment/dispatch.py:208-215) returns): x bf16 NHWC [N,H,W,32] -> float32 NCHW [N,O,H,W],
  * y = bias[o] + sum_c w[o,c] * bf16(relu(scale[c]*x + shift[c])); w is float32 [O,32] (bf16-representable values
