@@ -39,6 +39,10 @@ if files:
             return "fused_pointwise"
         if k.startswith("k_out_head"):
             return "out_head"
+        if k.startswith("k_conv1x1"):
+            return "conv1x1_mfma"
+        if k.startswith("k_first_conv"):
+            return "first_conv"
         return None
     groups_t = {}
     for k, a in agg.items():
@@ -68,7 +72,8 @@ def conv_group(k):  # same split as fused_unet._launch_unit: 128-output-channel 
 
 
 groups = {"conv3x3_mfma": lambda k: conv_group(k) == "conv3x3_mfma", "conv3x3_mfma_deep": lambda k: conv_group(k) == "conv3x3_mfma_deep",
-          "fused_pointwise": lambda k: k.startswith("k_fused_act"), "out_head": lambda k: k.startswith("k_out_head")}
+          "fused_pointwise": lambda k: k.startswith("k_fused_act"), "out_head": lambda k: k.startswith("k_out_head"),
+          "conv1x1_mfma": lambda k: k.startswith("k_conv1x1"), "first_conv": lambda k: k.startswith("k_first_conv")}
 out = {}
 with open(f"profiles/{tag}_pmc_hbm_traffic_summary.csv", "w") as f:
     w = csv.writer(f)
