@@ -173,7 +173,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int row0, i
   }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool TALL = false>
 struct ConvCfg {
   static constexpr int KC = CIN / 16;    // MFMA k-steps per tap
   static constexpr int NPL = CIN / 8;    // 16-byte channel-octet planes in LDS
@@ -181,7 +181,9 @@ struct ConvCfg {
   // register budget per wave (256 VGPRs at 2 waves/SIMD): 9*KC*4 for the weights + 16*R accumulators
   // + the next tile's staging loads + the residual prefetch
   static constexpr int R = CIN >= 64 ? 2 : 4;                      // output rows per wave and pass
-  static constexpr int PASSES = (CIN >= 64 && COUT >= 64) ? 2 : 1; // row passes per tile (accumulators reused)
+  // row passes per tile (accumulators reused); TALL doubles them: a taller tile has less halo per output row, taken
+  // when the image height is a multiple of the taller tile
+  static constexpr int PASSES = ((CIN >= 64 && COUT >= 64) ? 2 : 1) * (TALL ? 2 : 1);
   static constexpr int RG = 4 / NCB;                               // row groups per workgroup (4 waves)
   static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2;
   static constexpr int RAW = LH * LW;
@@ -199,9 +201,9 @@ struct ConvCfg {
 // PK > 0: the residual block's 1x1 projection of the block input (cellpose `resdown.proj`, BatchNorm folded into its
 // weights) is PK extra k-steps of the same accumulation: its raw input tile (no halo, no activation) is staged beside
 // the window and the projected tensor never exists in HBM.
-template <int CIN, int COUT, bool UP, bool POOL, int PK>
+template <int CIN, int COUT, bool UP, bool POOL, int PK, bool TALL>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
-  using cfg = ConvCfg<CIN, COUT>;
+  using cfg = ConvCfg<CIN, COUT, TALL>;
   constexpr int PPLANE = (cfg::TH * cfg::TW) | 1;  // slot pitch of a projection-input octet plane
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
   constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, PASSES = cfg::PASSES;
@@ -559,13 +561,9 @@ int launch_conv_dma(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   return ALIBY_OK;
 }
 
-template <int CIN, int COUT, bool UP>
-int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
-  // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
-  // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
-  static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
-  if (use_dma && !a.pool && !a.pin) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
-  using cfg = ConvCfg<CIN, COUT>;
+template <int CIN, int COUT, bool UP, bool TALL>
+int launch_conv_reg(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
+  using cfg = ConvCfg<CIN, COUT, TALL>;
   a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
   a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
   const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
@@ -575,12 +573,12 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   constexpr int PKV = (!UP && CIN == 32 && COUT == 32) ? 1 : ((!UP && CIN == 64 && COUT == 64) ? 2 : 0);  // projection input: 16 / 32 channels
   constexpr int P_BYTES = PKV ? 2 * PKV * ((cfg::TH * cfg::TW) | 1) * 16 : 0;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, 0>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, 0, TALL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true, 0>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true, 0, TALL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
     if constexpr (PKV > 0)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, PKV>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, PKV, TALL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES + P_BYTES));
     attr_done = true;
   }
@@ -589,18 +587,30 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   if (a.pin) {
     if constexpr (PKV > 0) {
       ARG_CHECK(!a.pool && a.pcs >= 1 && a.pcs <= 2 * PKV, "conv3x3: fused projection: unsupported input width");
-      hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, PKV>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES + P_BYTES, stream, a);
+      hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, PKV, TALL>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES + P_BYTES, stream, a);
     } else {
       aliby_set_error("conv3x3: fused projection is built for (32,32) and (64,64) without upsampling only");
       return ALIBY_ERR_UNSUPPORTED;
     }
   } else if (a.pool) {
-    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true, 0>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true, 0, TALL>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   } else {
-    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, 0>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, 0, TALL>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   }
   KERNEL_CHECK();
   return ALIBY_OK;
+}
+
+template <int CIN, int COUT, bool UP>
+int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
+  // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
+  // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
+  static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
+  if (use_dma && !a.pool && !a.pin) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
+  // a taller tile where it divides the image and fits two workgroups per CU (measured: 64->128 at 56 rows +10 %)
+  constexpr bool CAN_TALL = CIN >= 64 && COUT >= 128;
+  if (CAN_TALL && !a.pin && a.H % (2 * ConvCfg<CIN, COUT, false>::TH) == 0) return launch_conv_reg<CIN, COUT, UP, CAN_TALL>(ctx, a, stream);
+  return launch_conv_reg<CIN, COUT, UP, false>(ctx, a, stream);
 }
 
 }  // namespace

@@ -52,7 +52,7 @@ def _reference(x, w, scale, shift, bias, res, res_up, in_up):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("shape", [(3, 44, 70), (1, 10, 6), (2, 2, 34)])
+@pytest.mark.parametrize("shape", [(3, 44, 70), (1, 10, 6), (2, 2, 34), (2, 16, 40)])  # the last: a multiple of the tall tile
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
 def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up, shape):
     import torch
