@@ -380,7 +380,7 @@ struct DmaCfg {
   // ~760 TFLOP/s as two 64-channel K-slices and dropped; WAVES_PER_SIMD / PASSES keep the knobs it needed)
   static constexpr int WAVES_PER_SIMD = CIN >= 128 ? 1 : 2;
   static constexpr int R = CIN >= 64 ? 2 : 4;      // output rows per wave and pass
-  static constexpr int PASSES = CIN >= 128 ? 2 : 1;  // row passes per tile (accumulators reused): a taller tile, less halo
+  static constexpr int PASSES = (CIN >= 128 || COUT >= 128) ? 2 : 1;  // row passes per tile (accumulators reused): a taller tile, less halo
   static constexpr int RG = 4 / NCB;
   static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2;
   static constexpr int RAW = LH * LW;
