@@ -1,8 +1,9 @@
 """
 The segmentation network: a residual U-Net with a global style vector, in plain PyTorch-ROCm.
 
-This is the only part of the hot path that runs through PyTorch (north_star: "PyTorch-ROCm used only
-for the Cellpose U-Net forward pass"; MIOpen/hipBLASLt put the convolutions on the MFMA units).
+The module DEFINES the network (parameter layout, state_dict keys) and serves as the fp32 reference the GPU tests
+compare against; inference runs through `fused_unet.FusedUNet`, which executes the same arithmetic with the
+hand-written kernels of aliby_amd/csrc/nn_*.hip (north_star allowed PyTorch for this forward; nothing of it is left there).
 Architecture as published for Cellpose's U-Net family (nbase = [2, 32, 64, 128, 256], 3x3 kernels,
 pre-activation BatchNorm-ReLU-Conv units, two residual pairs per scale with a 1x1 projection, max-pool
 down, nearest up, additive skips, style = L2-normalised global average of the deepest map injected
