@@ -232,3 +232,31 @@ def test_radial_distribution_matches_oracle(engine, objset):
             torch.cuda.synchronize()
             ref = rr.get_radial_distribution(labels, planes[ch], bin_count=bin_count)
             _compare(names, out.cpu().numpy(), ref)
+
+
+def test_stream_fanout_is_bit_identical_to_single_stream(engine, monkeypatch):
+    """The feature families run on four side HIP streams (families._FanOut); a race between them would show up as a
+    difference against the single-stream evaluation of the same batch.  Also checks the asynchronous rows download."""
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.batch import extract_batch
+
+    fovs = [synth.make_fov(2, i, shape=(256, 320), n_channels=3, n_target=24) for i in range(3)]
+    px = torch.from_numpy(np.stack([f["pixels"] for f in fovs])).cuda()  # [F,C,1,Y,X]
+    labels = torch.from_numpy(np.stack([f["nuclei"] for f in fovs])).cuda()
+    mono = {"None": {"None": ["sizeshape"]}}
+    for c in range(3):
+        mono[c] = {"max": ["radial_zernikes", "intensity", "feret", "texture", "radial_distribution", "zernike"]}
+    multi = {(a, b): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}} for a in range(3) for b in range(a + 1, 3)}
+    results = {}
+    for n_streams in ("1", "4"):
+        monkeypatch.setenv("ALIBY_FEATURE_STREAMS", n_streams)
+        m1, names1, table = extract_batch(engine, labels, (px, _lib.U16), mono)
+        m2, names2, _ = extract_batch(engine, labels, (px, _lib.U16), multi, multi=True, table=table)
+        handle = engine.to_host_async((m1, m2), slot=int(n_streams) % 2)
+        a1, a2 = handle.wait()
+        results[n_streams] = (a1.copy(), a2.copy())
+        assert np.array_equal(a1, engine.to_host(m1), equal_nan=True)
+    for x, y in zip(results["1"], results["4"]):
+        assert x.shape == y.shape and x.shape[0] == table.n_obj
+        assert np.array_equal(x, y, equal_nan=True)
