@@ -185,7 +185,7 @@ int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const uint16_t* cur
  * (uint64: 0 tile start, 1 loads issued, 2 after barrier, 3 prologue done, 4 after barrier, 5 MFMA done,
  * 6 stores issued).  NULL switches it off (the default). */
 int aliby_debug_conv_trace(aliby_ctx* ctx, void* stamps_dev);
-/* The same unit with the residual block's 1x1 projection fused in (cellpose `resdown`: x = proj(x_in) + conv1(conv0(x_in))):
+/* The same unit (segment/dispatch.py:208-215) with the residual block's 1x1 projection fused in (cellpose `resdown`: x = proj(x_in) + conv1(conv0(x_in))):
  *   OUT = conv3x3( relu(scale*IN + shift) ) + bias + proj_w . PROJ_IN[n,y,x,:]
  * PROJ_IN is the block's RAW input [N,H,W,proj_channels] bf16 (no activation; the projection's BatchNorm is folded into
  * proj_w, its bias into `bias`), so the projected tensor never exists in HBM.  proj_wpk comes from
@@ -198,25 +198,27 @@ int aliby_nn_conv3x3_proj_bf16(aliby_ctx* ctx, const void* in, const void* wpk, 
  * ([COUT/32][9 taps][CIN/16][64 lanes][8] bf16, COUT*CIN*9*2 bytes; input channels >= CIN_src are zero). */
 int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk,
                                void* stream);
-/* float32 [COUT, CIN_src] device weights of a 1x1 convolution -> [COUT/32][CIN/16][64 lanes][8] bf16 (same row order). */
+/* Weight preparation for the two entries above (what the reference leaves to torch's module loading,
+ * segment/dispatch.py:161-175): float32 [COUT, CIN_src] device weights of a 1x1 convolution -> [COUT/32][CIN/16][64 lanes][8] bf16 (same row order). */
 int aliby_nn_pack_conv1x1_bf16(aliby_ctx* ctx, const float* w_oi, int COUT, int CIN_src, int CIN, void* wpk,
                                void* stream);
 /* network output bf16 NHWC [N,H,W,Cpad] (+ bias[Cout]) -> float32 NCHW [N,Cout,H,W]. */
 int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W, int Cpad, int Cout,
                               const float* bias, float* out, void* stream);
-/* 1x1 convolution of the network (cellpose `resdown.proj` / `resup.proj`: BatchNorm -> Conv2d(1x1), BatchNorm folded into
- * the weights by the caller): OUT[n,y,x,:] = W . IN[n,y,x,:] + bias, bf16 NHWC, hand-written MFMA GEMM over the N*H*W
+/* 1x1 convolution of the network that `model.eval` runs (segment/dispatch.py:208-215; cellpose `resdown.proj` /
+ * `resup.proj`: BatchNorm -> Conv2d(1x1), BatchNorm folded into the weights by the caller): OUT[n,y,x,:] = W . IN[n,y,x,:] + bias, bf16 NHWC, hand-written MFMA GEMM over the N*H*W
  * pixels.  wpk from aliby_nn_pack_conv1x1_bf16(COUT, CIN, CIN).  CIN in {32, 64, 128, 256}; COUT 32, 64 or a multiple of
  * 128; bias may be NULL. */
 int aliby_nn_conv1x1_bf16(aliby_ctx* ctx, const void* in, const void* wpk, const float* bias, void* out, int N, int H, int W,
                           int CIN, int COUT, void* stream);
-/* First layer of the network on float32 NCHW tiles with Cin <= 2 channels (the 2-channel input cellpose builds):
+/* First layer of the network that `model.eval` runs (segment/dispatch.py:208-215) on float32 NCHW tiles with Cin <= 2
+ * channels (the 2-channel input cellpose builds from the selected plane, dispatch.py:192-206):
  * c0 = conv3x3(bf16(relu(scale[c]*x + shift[c])), zero padded) as bf16 NHWC[32] WITHOUT the convolution's bias, and the raw
  * input as bf16 NHWC[8] (channels >= Cin zero) for the block's projection.  w_oihw: float32 [32, Cin, 3, 3] (pass bf16-
  * representable values to reproduce a bf16 convolution). */
 int aliby_nn_first_conv_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W, const float* scale,
                              const float* shift, const float* w_oihw, void* raw8, void* c0, void* stream);
-/* Style vector of the network (cellpose `make_style`: global average pool of the deepest feature map, L2-normalised) and
+/* Style vector of the network that `model.eval` runs (segment/dispatch.py:208-215; cellpose `make_style`: global average pool of the deepest feature map, L2-normalised) and
  * the per-sample shifts of every styled unit derived from it in one batched product: x bf16 NHWC [N,H,W,C] ->
  * style float32 [N,C]; shifts[n,:] = b + style[n,:] . wt, wt float32 [C,J] (`batchconvstyle.full` of all units, folded with
  * their BatchNorm by the caller), shifts float32 [N,J]. */
