@@ -16,6 +16,7 @@ ground truth into the same dynamics.
 
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -84,6 +85,45 @@ class CellposeModel:
             warnings.warn("CellposeModel: no pretrained weights available offline; the network is randomly "
                           "initialised and its masks are not meaningful (SURVEY.md §0.5).")
         self._geom_cache = {}
+        # Optional hipGraph replay of the network forward (~230 dependent launches per batch; the whole forward is kernels
+        # of this library on one stream with static shapes): captured once per batch shape, only when no per-kernel event
+        # timing is requested.  OFF by default: measured on config 2 it is 4 % SLOWER than eager launches (453 vs 473
+        # tiles/s) — the launches are long enough that the host stays ahead, and replay needs the batch copied into and
+        # out of the graph's static buffers.  ALIBY_NET_GRAPH=1 turns it on; a refused capture falls back to eager.
+        self.use_graph = os.environ.get("ALIBY_NET_GRAPH", "0") == "1"
+        self._graphs = {}
+
+    def _forward_batch(self, tiles_b: torch.Tensor, out_b: torch.Tensor) -> None:
+        """One network forward on a batch of tiles, written into out_b; graph replay when allowed."""
+        if not (self.use_graph and self.eng.profile is None):
+            self.fused(tiles_b, out=out_b)
+            return
+        key = tuple(tiles_b.shape)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in, static_out = torch.empty_like(tiles_b), torch.empty_like(out_b)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):  # warm-up: weight packing, function attributes, allocator pools
+                    static_in.copy_(tiles_b)
+                    self.fused(static_in, out=static_out)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self.fused(static_in, out=static_out)
+                entry = (graph, static_in, static_out)
+            except Exception as exc:  # capture refused: stay eager for this model
+                warnings.warn(f"network graph capture failed ({exc!r}); running eager")
+                self.use_graph = False
+                torch.cuda.synchronize()
+                self.fused(tiles_b, out=out_b)
+                return
+            self._graphs[key] = entry
+        graph, static_in, static_out = entry
+        static_in.copy_(tiles_b)
+        graph.replay()
+        out_b.copy_(static_out)
 
     # ------------------------------------------------------------------ reference-side helpers
     def select_and_project(self, pixels, channel: int) -> torch.Tensor:
@@ -162,7 +202,7 @@ class CellposeModel:
         with self.eng.timed("unet_forward"), torch.no_grad():
             for i in range(0, ntiles, self.batch_size):
                 if self.fused is not None and g["by"] % 8 == 0 and g["bx"] % 8 == 0:
-                    self.fused(tiles[i : i + self.batch_size], out=yt[i : i + self.batch_size])  # written in place
+                    self._forward_batch(tiles[i : i + self.batch_size], yt[i : i + self.batch_size])  # written in place
                 else:
                     xb = tiles[i : i + self.batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
                     yb, _ = self.net(xb)

@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--net-batch", type=int, default=288, help="224x224 tiles per U-Net forward (the reference's batch_size knob)")
     ap.add_argument("--time-every", type=int, default=7, help="bracket every n-th launch of the per-layer network kernels with HIP "
                     "events (they are launched ~600 times per step; 1 = every launch)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="informational: no per-kernel HIP events, so the network forward "
+                    "runs as a replayed hipGraph (the product path); the line then carries no roofline objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -174,7 +176,7 @@ def main():
     eng.profile = None
     for _ in range(args.warmup):
         step()[0].wait()
-    eng.profile = {}
+    eng.profile = None if args.no_kernel_timing else {}
     eng.profile_sample = {"conv3x3_mfma": args.time_every, "conv3x3_mfma_deep": args.time_every, "fused_pointwise": args.time_every}
     eng._sample_count = {}
     if model.fused is not None:
@@ -212,41 +214,43 @@ def main():
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - t0)
 
-    # ---- roofline of the dominant hand-written kernel group ----------------------------------------------
-    hip_groups = {k: v for k, v in prof.items() if k not in ("unet_forward", "rows_d2h")}
-    dominant = max(hip_groups, key=lambda k: hip_groups[k]["ms_total"])
-    launches = hip_groups[dominant]["launches"]
-    avg_ms = hip_groups[dominant]["ms_total"] / launches
-    ab = alg_bytes(dominant, B, C, Z, Y, X, table.n_obj, n_tiles_net)
-    timed_launches = hip_groups[dominant].get("timed_launches", launches)
-    if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the timed launches
-        ab = model.fused.bytes_moved / timed_launches
-    if dominant.startswith("conv3x3_mfma"):  # exact: input + residual read once, output (+ pooled) written once, per timed launch
-        ab = model.fused.conv_stats[dominant][0] / timed_launches
-    achieved = ab / (avg_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-    # FETCH_SIZE doubled on gfx950): measured offline, committed under profiles/, see profiles/pmc_traffic.json
-    traffic = None
-    pmc_file = ROOT / "profiles" / "pmc_traffic.json"
-    if pmc_file.exists():
-        traffic = json.loads(pmc_file.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
-    roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
-            "avg_launch_ms": round(avg_ms, 4), "launches": launches}
-    if dominant.startswith("conv3x3_mfma"):  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
-        roof["mfma_tflops"] = round(model.fused.conv_stats[dominant][1] / timed_launches / (avg_ms * 1e-3) / 1e12, 1)
-    roof["timed_launches"] = timed_launches
-    # the deep levels' launches of the same kernel (128 output channels, K/N-split): bound by the matrix cores
-    roof_deep = None
-    if "conv3x3_mfma_deep" in prof and prof["conv3x3_mfma_deep"].get("timed_launches"):
-        g = prof["conv3x3_mfma_deep"]
-        st = model.fused.conv_stats["conv3x3_mfma_deep"]
-        t_ms = g["ms_total"] / g["launches"]
-        tf = st[1] / g["timed_launches"] / (t_ms * 1e-3) / 1e12
-        roof_deep = {"bound": "mfma", "kernel": "conv3x3_mfma_deep", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                     "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(t_ms, 4), "launches": g["launches"],
-                     "timed_launches": g["timed_launches"],
-                     "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
+    roof = roof_deep = None
+    if prof:  # (--no-kernel-timing: nothing was bracketed)
+        # ---- roofline of the dominant hand-written kernel group ----------------------------------------------
+        hip_groups = {k: v for k, v in prof.items() if k not in ("unet_forward", "rows_d2h")}
+        dominant = max(hip_groups, key=lambda k: hip_groups[k]["ms_total"])
+        launches = hip_groups[dominant]["launches"]
+        avg_ms = hip_groups[dominant]["ms_total"] / launches
+        ab = alg_bytes(dominant, B, C, Z, Y, X, table.n_obj, n_tiles_net)
+        timed_launches = hip_groups[dominant].get("timed_launches", launches)
+        if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the timed launches
+            ab = model.fused.bytes_moved / timed_launches
+        if dominant.startswith("conv3x3_mfma"):  # exact: input + residual read once, output (+ pooled) written once, per timed launch
+            ab = model.fused.conv_stats[dominant][0] / timed_launches
+        achieved = ab / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+        # FETCH_SIZE doubled on gfx950): measured offline, committed under profiles/, see profiles/pmc_traffic.json
+        traffic = None
+        pmc_file = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc_file.exists():
+            traffic = json.loads(pmc_file.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
+                "avg_launch_ms": round(avg_ms, 4), "launches": launches}
+        if dominant.startswith("conv3x3_mfma"):  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
+            roof["mfma_tflops"] = round(model.fused.conv_stats[dominant][1] / timed_launches / (avg_ms * 1e-3) / 1e12, 1)
+        roof["timed_launches"] = timed_launches
+        # the deep levels' launches of the same kernel (128 output channels, K/N-split): bound by the matrix cores
+        roof_deep = None
+        if "conv3x3_mfma_deep" in prof and prof["conv3x3_mfma_deep"].get("timed_launches"):
+            g = prof["conv3x3_mfma_deep"]
+            st = model.fused.conv_stats["conv3x3_mfma_deep"]
+            t_ms = g["ms_total"] / g["launches"]
+            tf = st[1] / g["timed_launches"] / (t_ms * 1e-3) / 1e12
+            roof_deep = {"bound": "mfma", "kernel": "conv3x3_mfma_deep", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(t_ms, 4), "launches": g["launches"],
+                         "timed_launches": g["timed_launches"],
+                         "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
     net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(args.steps, 1)
     hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "out_head",
                                                                        "first_conv", "conv1x1_mfma", "style")) / max(args.steps, 1)
