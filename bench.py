@@ -177,7 +177,7 @@ def main():
     for _ in range(args.warmup):
         step()[0].wait()
     eng.profile = None if args.no_kernel_timing else {}
-    eng.profile_sample = {"conv3x3_mfma": args.time_every, "conv3x3_mfma_deep": args.time_every, "fused_pointwise": args.time_every}
+    eng.profile_sample = {k: args.time_every for k in ("conv3x3_mfma", "conv3x3_mfma_deep", "fused_pointwise", "conv1x1_mfma")}
     eng._sample_count = {}
     if model.fused is not None:
         model.fused.bytes_moved = 0
