@@ -607,8 +607,9 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
   static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
   if (use_dma && !a.pool && !a.pin) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
-  // a taller tile where it divides the image and fits two workgroups per CU (measured: 64->128 at 56 rows +10 %)
-  constexpr bool CAN_TALL = CIN >= 64 && COUT >= 128;
+  // a taller tile where it divides the image and fits two workgroups per CU (measured: 64->128 at 56 rows +10 %,
+  // 32->32 at 224 rows +3..7 %: the fixed per-tile latency chain is amortised over twice the pixels)
+  constexpr bool CAN_TALL = (CIN >= 64 && COUT >= 128) || (CIN == 32 && COUT == 32);
   if (CAN_TALL && !a.pin && a.H % (2 * ConvCfg<CIN, COUT, false>::TH) == 0) return launch_conv_reg<CIN, COUT, UP, CAN_TALL>(ctx, a, stream);
   return launch_conv_reg<CIN, COUT, UP, false>(ctx, a, stream);
 }
