@@ -73,6 +73,9 @@ _SIGNATURES = {
     "aliby_nn_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "aliby_track_stitch": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "aliby_debug_conv_trace": (_i, [_vp, _vp]),
+    "aliby_tiff_probe": (_i, [C.c_char_p, _vp, C.c_char_p, _i]),
+    "aliby_ingest_tiff_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
+    "aliby_ingest_inflate": (_i, [_i, _vp, _sz, _vp, _sz, _vp]),
     "aliby_nn_pack_conv3x3_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "aliby_nn_pack_conv1x1_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "aliby_nn_conv3x3_proj_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

@@ -163,3 +163,48 @@ def make_fov(config: int, fov: int = 0, shape=None, n_channels=None, n_z=None, n
     nuclei, cells, params = make_labels(rng, shape, nt)
     pixels = make_pixels(rng, cells, params, C, Z)
     return dict(pixels=pixels, nuclei=nuclei, cells=cells, params=params)
+
+
+def write_tiff(path, plane: np.ndarray, compression: str | None = None, rows_per_strip: int = 64) -> None:
+    """Minimal little-endian baseline TIFF writer (one 2-D grayscale page; no compression or Deflate) so that
+    synthetic stacks can be laid out on disk the way a microscope leaves them, one file per (t, c, z) plane."""
+    import struct
+    import zlib
+
+    plane = np.ascontiguousarray(plane)
+    assert plane.ndim == 2 and plane.dtype.kind in "uif" and plane.dtype.itemsize in (1, 2, 4)
+    h, w = plane.shape
+    strips = [plane[r : r + rows_per_strip].tobytes() for r in range(0, h, rows_per_strip)]
+    if compression == "deflate":
+        strips = [zlib.compress(s, 1) for s in strips]
+    elif compression is not None:
+        raise ValueError("compression must be None or 'deflate'")
+    n = len(strips)
+    data_at = 8
+    offsets, at = [], data_at
+    for s in strips:
+        offsets.append(at)
+        at += len(s) + (len(s) & 1)
+    arrays_at = at
+    offs_at, counts_at = (arrays_at, arrays_at + 4 * n) if n > 1 else (0, 0)
+    ifd_at = arrays_at + (8 * n if n > 1 else 0)
+    fmt = {"u": 1, "i": 2, "f": 3}[plane.dtype.kind]
+    tags = [
+        (256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, 8 * plane.dtype.itemsize), (259, 3, 1, 8 if compression else 1),
+        (262, 3, 1, 1), (273, 4, n, offs_at if n > 1 else offsets[0]), (277, 3, 1, 1), (278, 4, 1, rows_per_strip),
+        (279, 4, n, counts_at if n > 1 else len(strips[0])), (339, 3, 1, fmt),
+    ]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2sHI", b"II", 42, ifd_at))
+        for s in strips:
+            f.write(s)
+            if len(s) & 1:
+                f.write(b"\0")
+        if n > 1:
+            f.write(struct.pack(f"<{n}I", *offsets))
+            f.write(struct.pack(f"<{n}I", *(len(s) for s in strips)))
+        f.write(struct.pack("<H", len(tags)))
+        for tag, typ, count, value in tags:
+            f.write(struct.pack("<HHI", tag, typ, count))
+            f.write(struct.pack("<HH", value, 0) if typ == 3 and count == 1 else struct.pack("<I", value))
+        f.write(struct.pack("<I", 0))

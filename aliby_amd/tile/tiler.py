@@ -47,29 +47,7 @@ class TilerParameters:
         return cls(**kwargs)
 
 
-class ImageArray:
-    """Minimal Image: `.data` is a 5-D TCZYX array-like, `.meta` a dict (io/image.py contract)."""
-
-    def __init__(self, source, **kwargs):
-        if isinstance(source, dict):
-            source = source.get("array", source.get("path"))
-        if isinstance(source, (str, bytes)) or hasattr(source, "__fspath__"):
-            path = str(source)
-            if path.endswith(".npy"):
-                source = np.load(path, mmap_mode="r")
-            else:
-                raise NotImplementedError(
-                    "image ingest from TIFF/zarr (src/aliby/io/image.py) is SURVEY §8f-2 and not built; "
-                    "pass a TCZYX array or a .npy path as image_kwargs['source']"
-                )
-        if source.ndim != 5:
-            raise ValueError(f"expected a 5-D TCZYX array, got shape {source.shape}")
-        self.data = source
-        self.meta = dict(kwargs.get("meta", {}))
-
-
-def dispatch_image(source):
-    return ImageArray
+from aliby_amd.io.image import ImageArray, dispatch_image  # noqa: E402,F401  (re-exported: pipe_core imports them from here)
 
 
 def dispatch_tiler(kind, kwargs: dict):
@@ -108,6 +86,7 @@ class Tiler:
         self.no_processed = 0
         self._dev_stack = {}  # tp -> device [C,Z,Y,X] (keeps the last two, like load_image's lru_cache(2))
         self._engine = None
+        self._ingest_stream = self._ingest_pool = self._ingest_pending = None
 
     @classmethod
     def from_image(cls, image, parameters, **kwargs):
@@ -189,21 +168,58 @@ class Tiler:
 
         if tp in self._dev_stack:
             return self._dev_stack[tp]
-        block = self.pixels[tp]
-        if hasattr(block, "compute"):
-            block = block.compute(scheduler="synchronous")
-        if isinstance(block, torch.Tensor):
-            dev = block.cuda()
+        dev = self._ingest(tp)
+        if dev is not None:
+            pass
         else:
-            block = np.ascontiguousarray(block)
-            if block.dtype != np.uint16:
-                raise NotImplementedError(
-                    f"stager handles uint16 stacks (the reference's fixtures, SURVEY §3.3); got {block.dtype}"
-                )
-            dev = torch.from_numpy(block).cuda()
+            dev = self._upload(self.pixels[tp])
         if len(self._dev_stack) >= 2:
             self._dev_stack.pop(next(iter(self._dev_stack)))
         self._dev_stack[tp] = dev
+        return dev
+
+    def _upload(self, block):
+        import torch
+
+        if hasattr(block, "compute"):
+            block = block.compute(scheduler="synchronous")
+        if isinstance(block, torch.Tensor):
+            return block.cuda()
+        block = np.ascontiguousarray(block)
+        if block.dtype != np.uint16:
+            raise NotImplementedError(
+                f"stager handles uint16 stacks (the reference's fixtures, SURVEY §3.3); got {block.dtype}"
+            )
+        return torch.from_numpy(block).cuda()
+
+    def _ingest(self, tp: int):
+        """File-backed stacks (aliby_amd/io/image.py): decode + upload through csrc/ingest.hip on a side stream, and
+        start decoding the next time point on a helper thread while this one is being processed."""
+        import torch
+
+        pixels = self.pixels
+        if not hasattr(pixels, "read_device") or np.dtype(pixels.dtype) != np.uint16:
+            return None
+        from aliby_amd.extraction.engine import FeatureEngine
+
+        if self._engine is None:
+            self._engine = FeatureEngine()
+        if self._ingest_stream is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._ingest_stream = torch.cuda.Stream()
+            self._ingest_pool = ThreadPoolExecutor(max_workers=1)
+        ctx, stream = self._engine.ctx.handle, self._ingest_stream.cuda_stream
+        pending, self._ingest_pending = self._ingest_pending, None
+        dev = None
+        if pending is not None:
+            got = pending[1].result()  # the helper owns the staging block until it is done
+            if pending[0] == tp:
+                dev = got
+        if dev is None:
+            dev = pixels.read_device(tp, ctx, stream)
+        if dev is not None and tp + 1 < pixels.shape[0]:
+            self._ingest_pending = (tp + 1, self._ingest_pool.submit(pixels.read_device, tp + 1, ctx, stream))
         return dev
 
     def rects(self, tp: int) -> np.ndarray:

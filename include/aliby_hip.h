@@ -329,6 +329,27 @@ int aliby_object_ranks(aliby_ctx* ctx, const uint16_t* labels, const void* plane
                        int Y, int X, int channel, const aliby_object* table_dev, int n_obj, int max_area,
                        uint32_t* ranks_dev, int32_t* rmax_dev, void* stream);
 
+/* ---- §8f-2: image ingest --------------------------------------------------- */
+/* Host-side TIFF decode feeding the stager (aliby_crop_pad_u16).  Replaces the per-file imageio.imread of
+ * ImageList.get_data_lazy (src/aliby/io/image.py:395-408), the dask.array.image.imread of ImageDir /
+ * ImageMultiTiff (image.py:190, 285) and zarr's chunk decompression behind ImageZarr (image.py:246-259).
+ * Baseline TIFF 6.0 and BigTIFF; strips or tiles; compression none / LZW / Deflate / PackBits / Zstandard;
+ * horizontal predictor; sample 0 of chunky multi-sample pixels.
+ * aliby_tiff_probe: info[12] = pages, width, height, bits, sample_format (1 uint, 2 int, 3 float),
+ * samples_per_pixel, compression, predictor, tiled, bigtiff, big_endian, uniform; description receives page 0's
+ * ImageDescription (ImageJ hyperstack layout).  Needs no context and no GPU. */
+int aliby_tiff_probe(const char* path, int64_t* info, char* description, int description_len);
+/* Decode page pages[i] of paths[i] (i < n) into dst + i * plane_stride with a pool of n_threads host threads
+ * (<= 0: one per core, at most 16).  dst_is_device = 0: dst is host memory, ctx and stream may be NULL.
+ * dst_is_device = 1: every plane is decoded into pinned staging memory and queued for upload on `stream` as soon as
+ * its thread finishes, so transfers overlap the remaining decodes; returns after the last upload completed. */
+int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int32_t* pages, int n, int width,
+                             int height, int bytes_per_sample, void* dst, size_t plane_stride, int dst_is_device,
+                             int n_threads, void* stream);
+/* One compressed zarr chunk -> dst; codec 0 = zlib / gzip, 1 = Zstandard (libzstd.so.1 loaded on first use). */
+int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
+                         size_t* out_bytes);
+
 #ifdef __cplusplus
 }
 #endif
