@@ -73,6 +73,14 @@ _SIGNATURES = {
     "aliby_nn_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "aliby_track_stitch": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "aliby_debug_conv_trace": (_i, [_vp, _vp]),
+    "aliby_trap_gauss1d": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "aliby_trap_warp": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, C.c_double, _vp]),
+    "aliby_trap_entropy": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aliby_trap_morph": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "aliby_trap_label": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "aliby_trap_region_sums": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "aliby_trap_match_template": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, C.c_double, C.c_double, _vp]),
+    "aliby_trap_maxfilter1d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aliby_tiff_probe": (_i, [C.c_char_p, _vp, C.c_char_p, _i]),
     "aliby_ingest_tiff_planes": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _i, _vp]),
     "aliby_ingest_inflate": (_i, [_i, _vp, _sz, _vp, _sz, _vp]),

@@ -208,3 +208,23 @@ def write_tiff(path, plane: np.ndarray, compression: str | None = None, rows_per
             f.write(struct.pack("<HHI", tag, typ, count))
             f.write(struct.pack("<HH", value, 0) if typ == 3 and count == 1 else struct.pack("<I", value))
         f.write(struct.pack("<I", 0))
+
+
+def trap_image(seed: int = 11, shape=(512, 512), spacing: int = 128, first: int = 96, jitter: int = 6):
+    """Brightfield-like frame with a jittered grid of identical 'traps' (a textured ellipse with a bright bar on one
+    side, so that rotations of the template differ) on a flat, weakly noisy background — the input of trap detection
+    (config 4).  Returns (uint16 image, list of (y, x) centres)."""
+    rng = np.random.default_rng(seed)
+    img = 3000 + rng.normal(0, 30, shape)
+    yy, xx = np.mgrid[0 : shape[0], 0 : shape[1]]
+    centres = []
+    for cy in range(first, shape[0], spacing):
+        for cx in range(first, shape[1], spacing):
+            y = cy + int(rng.integers(-jitter, jitter + 1))
+            x = cx + int(rng.integers(-jitter, jitter + 1))
+            centres.append((y, x))
+            inside = ((yy - y) / 26.0) ** 2 + ((xx - x) / 20.0) ** 2 <= 1
+            img[inside] += rng.normal(0, 900, int(inside.sum())) + 1500
+            bar = (np.abs(yy - (y - 14)) <= 3) & (np.abs(xx - x) <= 16)
+            img[bar] += 4000
+    return np.clip(img, 0, 65535).astype(np.uint16), centres

@@ -8,8 +8,8 @@ aliby_amd/csrc/stager.hip through the C ABI (aliby_crop_pad_u16); the returned N
 registered in aliby_amd.devcache so that segment/extract steps reuse the device copy.
 
 Drift estimation (`find_drift`, phase cross-correlation) runs on the GPU when `calculate_drift` is set
-(aliby_amd/tile/drift.py).  Out of scope this round: trap detection (`segment_traps`).  With `tile_size` set, tile centres must be given through
-`trap_locations=[(y,x), ...]`; otherwise the reference's own fallback (one centre tile) is used.
+(aliby_amd/tile/drift.py).  With `tile_size` set, tile centres come from trap detection on the first frame
+(`segment_traps`, aliby_amd/tile/traps.py) unless `trap_locations=[(y,x), ...]` are given.
 """
 
 from __future__ import annotations
@@ -147,19 +147,26 @@ class Tiler:
         return {"drift": self.tile_locs.to_dict(tp), "pixels": self.get_fczyx(tp)}
 
     def _areas_of_interest(self):
-        """set_areas_of_interest (tiler.py:653-696) with explicit centres instead of trap detection."""
+        """set_areas_of_interest (tiler.py:653-696): trap detection on the first frame of the reference channel
+        (aliby_amd/tile/traps.py), centres too close to an edge dropped; explicit `trap_locations=[(y, x), ...]` take
+        the detector's place when given."""
         shape = self.pixels.shape[-2:]
         tmin = min(self.tile_size)
-        if self._trap_locations is not None and min(shape) // 2 > tmin // 2:
-            half, max_size = tmin // 2, min(shape)
-            locs = [
-                [a, b]
-                for a, b in self._trap_locations
-                if half < a < max_size - half and half < b < max_size - half
-            ]
-            return TileLocations.from_tiler_init(locs, self.tile_size, max_size)
         if min(shape) // 2 > tmin // 2:
-            warnings.warn("Trap detection is not built (SURVEY §8f-3), falling back to center tile.")
+            half, max_size = tmin // 2, min(shape)
+            if self._trap_locations is not None:
+                found = self._trap_locations
+            else:
+                from aliby_amd.tile.traps import segment_traps
+
+                try:
+                    initial = np.asarray(self.pixels[0, self.ref_channel_index, getattr(self, "ref_z", 0)])
+                    found = segment_traps(initial, tmin)
+                except Exception as e:
+                    warnings.warn(f"Trap detection failed ({e}), falling back to center tile.")
+                    return get_center(self.pixels.shape)
+            locs = [[int(a), int(b)] for a, b in found if half < a < max_size - half and half < b < max_size - half]
+            return TileLocations.from_tiler_init(locs, self.tile_size, max_size)
         return get_center(self.pixels.shape)
 
     # --------------------------------------------------------------------- pixels

@@ -350,6 +350,30 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
 int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
                          size_t* out_bytes);
 
+/* ---- §8f-3: trap detection -------------------------------------------------- */
+/* Building blocks of segment_traps / identify_trap_locations (src/aliby/tile/process_traps.py:24-218), each standing
+ * in for one scikit-image call of that file; float64 images, once per position.  aliby_amd/tile/traps.py sequences them.
+ * gauss1d: one axis of transform.rescale's anti-aliasing filter (scipy gaussian_filter, mode 'mirror'; truncate = 1
+ *   reproduces the integer frame's truncation).  warp: bilinear transform.warp with the 2x3 matrix acting on (col,row),
+ *   mode 0 constant / 1 reflect (rescale, rotate).  entropy: filters.rank.entropy with disk(radius).  morph: k x k
+ *   max / min (morphology.closing with square(k)).  label: measure.label, 8-connected, label = 1 + raster index of the
+ *   first pixel.  region_sums: raw moments per label for regionprops centroid / major_axis_length, and the border flag of
+ *   segmentation.clear_border.  match_template: feature.match_template on the median-padded image.  maxfilter1d: the
+ *   window maximum of feature.peak_local_max. */
+int aliby_trap_gauss1d(aliby_ctx* ctx, const double* in, double* out, int H, int W, int axis,
+                       const double* weights_dev, int radius, int truncate, void* stream);
+int aliby_trap_warp(aliby_ctx* ctx, const double* in, int H, int W, double* out, int OH, int OW,
+                    const double* matrix6_host, int mode, double cval, void* stream);
+int aliby_trap_entropy(aliby_ctx* ctx, const uint8_t* in, int H, int W, int radius, double* out, void* stream);
+int aliby_trap_morph(aliby_ctx* ctx, const uint8_t* in, uint8_t* out, int H, int W, int lo, int hi, int is_max,
+                     void* stream);
+int aliby_trap_label(aliby_ctx* ctx, const uint8_t* bw, int H, int W, int32_t* labels, void* stream);
+int aliby_trap_region_sums(aliby_ctx* ctx, const int32_t* labels, int H, int W, uint64_t* sums, void* stream);
+int aliby_trap_match_template(aliby_ctx* ctx, const double* padded, int PH, int PW, const double* templ, int th,
+                              int tw, double* out, int H, int W, double t_mean, double t_ssd, void* stream);
+int aliby_trap_maxfilter1d(aliby_ctx* ctx, const double* in, double* out, int H, int W, int axis, int radius,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
