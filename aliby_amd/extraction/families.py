@@ -196,6 +196,11 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
         kw = dict(cp_measure_kwargs.get(metric, {}))
         reg = MULTI if (multi and inst[1] == "None") else MONO
         if metric not in reg:
+            if metric == "granularity":
+                raise NotImplementedError(
+                    "cp_measure's 'granularity' (not in the builder's default feature list, pipe_builder.py:49-56) is not "
+                    "built: see DESIGN.md §7"
+                )
             raise KeyError(metric)
         names = reg[metric]["names"](kw)
         blocks.append((col, names))
