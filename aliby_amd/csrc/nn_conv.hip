@@ -78,6 +78,7 @@ struct ConvArgs {
   int cs, coff;        // input pixel stride and first staged octet, in 16-byte units (a channel slice of a wider tensor)
   int ocs, ocoff;      // the same for OUT / RES / POOL (an output-channel slice of a wider tensor)
   int N, H, W;
+  int G;               // packed launches: images laid side by side per tile row (G * W = 224); 1 otherwise
   int tiles_x, tiles_y, ntiles;
   const uint4* pin;    // fused 1x1 projection: raw input [N, H, W, pcs*8] bf16 (NULL: none)
   const uint4* pwpk;   // its packed weights ([cout block][k-step][lane]); the projection's bias rides in `bias`
@@ -101,13 +102,13 @@ struct ConvArgs {
 // residual rows of one pass: R rows x 32 bytes per lane, from clamped addresses (rows / columns past the image edge
 // are loaded but never stored)
 template <int R>
-__device__ __forceinline__ void conv_load_res(const ConvArgs& a, int n, int row0, int gx, int c0, uint4 (&rr)[R][2]) {
+__device__ __forceinline__ void conv_load_res(const ConvArgs& a, int n, int irow, int row0, int gx, int c0, uint4 (&rr)[R][2]) {
   const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
   const uint4* resN = a.res + (size_t)n * RH * RW * a.ocs + a.ocoff;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int cy = min(row0 + r, a.H - 1), cx = min(gx, a.W - 1);
-    const unsigned off = (unsigned)(((cy >> a.res_up) * RW + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
+    const unsigned off = (unsigned)((((irow + cy) >> a.res_up) * RW + (cx >> a.res_up)) * a.ocs + (c0 >> 3));
     rr[r][0] = resN[off];
     rr[r][1] = resN[off + 1];
   }
@@ -159,13 +160,13 @@ __device__ __forceinline__ void conv_mfma(const bf16x8_t* L, const bf16x8_t (&wf
 
 // epilogue: fp32 -> bf16, 32 contiguous bytes per lane and row
 template <int R>
-__device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int row0, int gx, int c0, const f32x16_t (&acc)[R]) {
+__device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int irow, int row0, int gx, int c0, const f32x16_t (&acc)[R]) {
   if (gx >= a.W) return;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int gy = row0 + r;
     if (gy >= a.H) continue;
-    uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)((gy * a.W + gx) * a.ocs + (c0 >> 3));
+    uint4* op = a.out + (size_t)n * a.H * a.W * a.ocs + a.ocoff + (unsigned)(((irow + gy) * a.W + gx) * a.ocs + (c0 >> 3));
     op[0] = make_uint4(cv_pack2(acc[r][0], acc[r][1]), cv_pack2(acc[r][2], acc[r][3]),
                        cv_pack2(acc[r][4], acc[r][5]), cv_pack2(acc[r][6], acc[r][7]));
     op[1] = make_uint4(cv_pack2(acc[r][8], acc[r][9]), cv_pack2(acc[r][10], acc[r][11]),
@@ -173,7 +174,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int row0, i
   }
 }
 
-template <int CIN, int COUT, bool TALL = false>
+template <int CIN, int COUT, bool TALL = false, bool PACK = false>
 struct ConvCfg {
   static constexpr int KC = CIN / 16;    // MFMA k-steps per tap
   static constexpr int NPL = CIN / 8;    // 16-byte channel-octet planes in LDS
@@ -185,7 +186,8 @@ struct ConvCfg {
   // when the image height is a multiple of the taller tile
   static constexpr int PASSES = ((CIN >= 64 && COUT >= 64) ? 2 : 1) * (TALL ? 2 : 1);
   static constexpr int RG = 4 / NCB;                               // row groups per workgroup (4 waves)
-  static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2;
+  // PACK: one more window column, the zero column that separates two images meeting inside the 32-pixel block
+  static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2 + (PACK ? 1 : 0);
   static constexpr int RAW = LH * LW;
   // plane pitch in 16-byte slots, chosen so that the 8-lane groups of ds_write_b128 (lanes = NPL octets x
   // 8/NPL pixels) land on 8 distinct slots of the 128-byte bank window
@@ -201,9 +203,17 @@ struct ConvCfg {
 // PK > 0: the residual block's 1x1 projection of the block input (cellpose `resdown.proj`, BatchNorm folded into its
 // weights) is PK extra k-steps of the same accumulation: its raw input tile (no halo, no activation) is staged beside
 // the window and the projected tensor never exists in HBM.
-template <int CIN, int COUT, bool UP, bool POOL, int PK, bool TALL>
+//
+// PACK: the deep levels' images are 28 / 56 / 112 pixels wide, which leaves a 32-pixel MFMA block 12.5 % empty.  A packed
+// launch lays G = 224 / W images side by side (a view: image g of a group starts G rows of pointers further, nothing is
+// copied) and cuts that 224-pixel row into seven full blocks.  A block then holds the end of one image and the start of
+// the next: the staging puts one zero column between them in LDS (the right halo of the first and the left halo of the
+// second), lanes past the seam read one slot further, and every lane keeps its own (image, column) for the residual,
+// the store and the pooled output.
+template <int CIN, int COUT, bool UP, bool POOL, int PK, bool TALL, bool PACK = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
-  using cfg = ConvCfg<CIN, COUT, TALL>;
+  static_assert(!PACK || (!UP && PK == 0), "packed launches: plain input, no fused projection");
+  using cfg = ConvCfg<CIN, COUT, TALL, PACK>;
   constexpr int PPLANE = (cfg::TH * cfg::TW) | 1;  // slot pitch of a projection-input octet plane
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
   constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, PASSES = cfg::PASSES;
@@ -248,19 +258,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
+    // packed: the block starts at column cst of image g0 of group n; the seam (if any) is before block pixel kb
+    int g0 = 0, cst = x0, kb = 1 << 20, nimg = n;
+    if constexpr (PACK) {
+      g0 = x0 / a.W;
+      cst = x0 - g0 * a.W;
+      kb = a.W - cst;
+      nimg = n * a.G;
+    }
 
-    f32x2_t sh[4];
+    f32x2_t sh[4], sh1[PACK ? 4 : 1];
     {
-      const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
+      const float* sp = a.shift + (size_t)(nimg + g0) * a.shift_stride + pl * 8;
 #pragma unroll
       for (int k = 0; k < 4; ++k) sh[k] = f32x2_t{sp[2 * k], sp[2 * k + 1]};
+      if constexpr (PACK) {
+        const float* sq = a.shift + (size_t)(nimg + min(g0 + 1, a.G - 1)) * a.shift_stride + pl * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh1[k] = f32x2_t{sq[2 * k], sq[2 * k + 1]};
+      }
     }
     // ---- residual rows and bias seed the accumulators: requested now, unpacked after the prologue
-    const int gx = x0 + px;
+    const int second = (PACK && px >= kb) ? 1 : 0;  // this lane's pixel belongs to image g0 + 1
+    const int gx = PACK ? (second ? px - kb : cst + px) : x0 + px;
+    const int irow = PACK ? (g0 + second) * a.H : 0;
     const int c0 = cb * 32 + hh * 16;
     // (pass 0 before the prologue, pass p+1 while pass p is on the matrix cores: one pass worth of registers)
     uint4 rr[R][2];
-    auto load_res = [&](int pass) { conv_load_res<R>(a, n, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
+    auto load_res = [&](int pass) { conv_load_res<R>(a, nimg, irow, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
     if (a.res) load_res(0);
     CONV_STAMP(1);
     __syncthreads();  // every wave is done reading the previous tile's planes
@@ -268,28 +293,52 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     // ---- stage the raw window: BATCH 16-byte loads per thread in flight at once (unconditional, from clamped
     // addresses: no divergent branch around a load), then the prologue (BatchNorm affine + style shift + ReLU,
     // bf16; the convolution's zero padding is applied AFTER the activation) into the LDS planes
-    const uint4* inN = a.in + (size_t)n * IH * IW * a.cs + a.coff;  // uniform base (SGPR pair) + 32-bit lane offsets
+    const uint4* inN = a.in + (size_t)nimg * IH * IW * a.cs + a.coff;  // uniform base (SGPR pair) + 32-bit lane offsets
     int p0 = pix0, qy = ly0, qx = lx0;
     asm volatile("" : "+v"(p0), "+v"(qy), "+v"(qx));  // recompute the window coordinates per tile: 3 registers, not 2*ITERS
 #pragma unroll
     for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
       uint4 v[BATCH];
-      unsigned inside = 0;
+      unsigned inside = 0, later = 0;
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         if (it0 + u >= ITERS) break;
         // pixel p0 + it*PIX_PER_IT of the window raster, without a division: constant row / column advance + one wrap
         int lx = qx + ((it0 + u) * PIX_PER_IT) % LW, ly = qy + ((it0 + u) * PIX_PER_IT) / LW;
         if (lx >= LW) { lx -= LW; ly += 1; }
-        const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
-        inside |= (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W) << u;
-        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gxi, 0), a.W - 1);
-        v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * a.cs + pl)];
+        const int gy = y0 - 1 + ly;
+        const int cy = min(max(gy, 0), a.H - 1);
+        if constexpr (PACK) {
+          // window slot -> block pixel -1..32 (slot `gapi` is the seam's zero column, or the unused last slot) -> (image, column)
+          const int gapi = kb < 32 ? kb + 1 : TW + 2;
+          const int bp = lx - 1 - (lx > gapi ? 1 : 0);
+          const int snd = bp >= kb ? 1 : 0;
+          const int c = snd ? bp - kb : cst + bp;
+          // (a halo pixel must lie in the image of the block pixel it borders: kb == 32 puts the right halo in the next image)
+          const bool ok = lx != gapi && c >= 0 && c < a.W && !(bp == TW && kb == TW) && (unsigned)gy < (unsigned)a.H;
+          const int img = (snd && ok) ? g0 + 1 : g0;
+          inside |= (unsigned)ok << u;
+          later |= (unsigned)snd << u;
+          v[u] = inN[(unsigned)(((img * a.H + cy) * IW + min(max(c, 0), a.W - 1)) * a.cs + pl)];
+        } else {
+          const int gxi = x0 - 1 + lx;
+          inside |= (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W) << u;
+          const int cx = min(max(gxi, 0), a.W - 1);
+          v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * a.cs + pl)];
+        }
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
         if (it0 + u >= ITERS) break;
-        const uint4 o = conv_act8(v[u], sc, sh, 0u - ((inside >> u) & 1u));
+        uint4 o;
+        if constexpr (PACK) {  // the style shift is per image
+          f32x2_t shs[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) shs[k] = ((later >> u) & 1u) ? sh1[k] : sh[k];
+          o = conv_act8(v[u], sc, shs, 0u - ((inside >> u) & 1u));
+        } else {
+          o = conv_act8(v[u], sc, sh, 0u - ((inside >> u) & 1u));
+        }
         if (it0 + u == ITERS - 1 && p0 + (it0 + u) * PIX_PER_IT >= RAW) continue;  // only the last round can run past the window
         lds[pl * PLANE + p0 + (it0 + u) * PIX_PER_IT] = o;
       }
@@ -329,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       if (pass + 1 < PASSES && a.res) load_res(pass + 1);
       __builtin_amdgcn_sched_barrier(0);
       conv_mfma<R, KC, (POOL ? cfg::DEPTH_POOL : cfg::DEPTH), PLANE, LW>(
-          reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px, wfrag, acc);
+          reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px + second, wfrag, acc);
       if constexpr (PK > 0) {
         const bf16x8_t* LP = reinterpret_cast<const bf16x8_t*>(ldsP) + hh * PPLANE + rbase * TW + px;
 #pragma unroll
@@ -339,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
             acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfrag[k], LP[2 * k * PPLANE + r * TW], acc[r], 0, 0, 0);
       }
       if (pass == PASSES - 1) CONV_STAMP(5);
-      conv_store<R>(a, n, y0 + rbase, gx, c0, acc);
+      conv_store<R>(a, nimg, irow, y0 + rbase, gx, c0, acc);
       // ---- the next level's input, max_pool2d(OUT, 2, 2), straight from the accumulators: row pairs are in this
       // wave's registers, column pairs are neighbouring lanes (max commutes with the bf16 rounding)
       if constexpr (POOL) {
@@ -348,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
         for (int r = 0; r < R; r += 2) {
           const int gy = y0 + rbase + r;
           const bool writer = (px & 1) == 0 && gx + 1 < a.W && gy + 1 < a.H;
-          uint4* pp = a.pool + (size_t)n * PH * PW * a.ocs + a.ocoff + (unsigned)(((gy >> 1) * PW + (gx >> 1)) * a.ocs + (c0 >> 3));
+          uint4* pp = a.pool + (size_t)nimg * PH * PW * a.ocs + a.ocoff + (unsigned)((((irow + gy) >> 1) * PW + (gx >> 1)) * a.ocs + (c0 >> 3));
 #pragma unroll
           for (int half = 0; half < 2; ++half) {  // 8 channels at a time: few live registers beside the resident weights
             unsigned pk[4];
@@ -472,7 +521,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       for (int q = 0; q < 4; ++q) b4[q] = bp[q];
     }
     uint4 rr[R][2];
-    auto load_res = [&](int pass) { conv_load_res<R>(a, n, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
+    auto load_res = [&](int pass) { conv_load_res<R>(a, n, 0, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
     if (a.res) load_res(0);
     CONV_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
@@ -511,7 +560,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       if (pass == 0) CONV_STAMP(4);
       conv_mfma<R, KC, cfg::DEPTH, PLANE, LW>(reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px, wfrag, acc);
       if (pass == PASSES - 1) CONV_STAMP(5);
-      conv_store<R>(a, n, y0 + rbase, gx, c0, acc);
+      conv_store<R>(a, n, 0, y0 + rbase, gx, c0, acc);
     }
     CONV_STAMP(6);
   }
@@ -561,21 +610,22 @@ int launch_conv_dma(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   return ALIBY_OK;
 }
 
-template <int CIN, int COUT, bool UP, bool TALL>
+template <int CIN, int COUT, bool UP, bool TALL, bool PACK = false>
 int launch_conv_reg(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
-  using cfg = ConvCfg<CIN, COUT, TALL>;
-  a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
+  using cfg = ConvCfg<CIN, COUT, TALL, PACK>;
+  a.G = PACK ? 224 / a.W : 1;
+  a.tiles_x = PACK ? 224 / cfg::TW : (a.W + cfg::TW - 1) / cfg::TW;
   a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
-  const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
+  const long long nt = (long long)(a.N / a.G) * a.tiles_x * a.tiles_y;
   ARG_CHECK(nt < INT_MAX, "conv3x3: too many tiles");
   a.ntiles = (int)nt;
   static bool attr_done = false;
-  constexpr int PKV = (!UP && CIN == 32 && COUT == 32) ? 1 : ((!UP && CIN == 64 && COUT == 64) ? 2 : 0);  // projection input: 16 / 32 channels
+  constexpr int PKV = PACK ? 0 : (!UP && CIN == 32 && COUT == 32) ? 1 : ((!UP && CIN == 64 && COUT == 64) ? 2 : 0);  // projection input: 16 / 32 channels
   constexpr int P_BYTES = PKV ? 2 * PKV * ((cfg::TH * cfg::TW) | 1) * 16 : 0;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, 0, TALL>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, 0, TALL, PACK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true, 0, TALL>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, true, 0, TALL, PACK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
     if constexpr (PKV > 0)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, PKV, TALL>),
@@ -593,9 +643,9 @@ int launch_conv_reg(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
       return ALIBY_ERR_UNSUPPORTED;
     }
   } else if (a.pool) {
-    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true, 0, TALL>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true, 0, TALL, PACK>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   } else {
-    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, 0, TALL>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, 0, TALL, PACK>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   }
   KERNEL_CHECK();
   return ALIBY_OK;
@@ -610,6 +660,14 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // a taller tile where it divides the image and fits two workgroups per CU (measured: 64->128 at 56 rows +10 %,
   // 32->32 at 224 rows +3..7 %: the fixed per-tile latency chain is amortised over twice the pixels)
   constexpr bool CAN_TALL = (CIN >= 64 && COUT >= 128) || (CIN == 32 && COUT == 32);
+  // images narrower than the 224-pixel level-0 tile are packed side by side so that no MFMA column runs empty
+  if constexpr (!UP && COUT >= 128) {
+    static const bool pack_on = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) != 0 : true; }();
+    if (pack_on && !a.pin && (a.W == 28 || a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0) {
+      if (a.H % (2 * ConvCfg<CIN, COUT, false>::TH) == 0) return launch_conv_reg<CIN, COUT, UP, true, true>(ctx, a, stream);
+      return launch_conv_reg<CIN, COUT, UP, false, true>(ctx, a, stream);
+    }
+  }
   if (CAN_TALL && !a.pin && a.H % (2 * ConvCfg<CIN, COUT, false>::TH) == 0) return launch_conv_reg<CIN, COUT, UP, CAN_TALL>(ctx, a, stream);
   return launch_conv_reg<CIN, COUT, UP, false>(ctx, a, stream);
 }

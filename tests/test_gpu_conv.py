@@ -78,6 +78,36 @@ def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up, shape):
         assert torch.equal(pool.float(), ref_pool)
 
 
+@pytest.mark.parametrize("shape", [(8, 28, 28), (16, 28, 28), (4, 56, 56), (8, 56, 56), (2, 112, 112), (4, 112, 112),
+                                   (3, 56, 56), (7, 28, 28)])  # the last two: not a whole group, plain launch
+@pytest.mark.parametrize("res_up", [False, True])
+def test_conv_unit_packed_deep_level_images(engine, shape, res_up):
+    """64 -> 128 on 28 / 56 / 112-pixel images: G = 224 / W images share a tile row, blocks straddle two images
+    (per-image style shift, residual, store and pooled output on either side of the seam)."""
+    import torch
+
+    torch.backends.cudnn.allow_tf32 = False
+    n, H, W = shape
+    cin, cout = 64, 128
+    g = torch.Generator().manual_seed(n * 1000 + W)
+    x = torch.randint(-1, 3, (n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
+    scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
+    rh, rw = (H // 2, W // 2) if res_up else (H, W)
+    res = torch.randint(-3, 4, (n, rh, rw, cout), generator=g).to(torch.bfloat16).cuda()
+    pool = torch.full((n, H // 2, W // 2, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    for use_pool in (None, pool):
+        for sh in (shift, shift[0].contiguous()):
+            out = _run(engine, x, w, scale, sh, bias, res, res_up, False, H, W, pool=use_pool)
+            ref = _reference(x, w, scale, sh, bias, res, res_up, False)
+            assert float(ref.abs().max()) <= 256
+            assert torch.equal(out.float(), ref)
+    ref_pool = torch.nn.functional.max_pool2d(ref.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(pool.float(), ref_pool)
+
+
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
 def test_conv_unit_random_data_full_tile_shapes(engine, cin, cout, in_up):
     import torch
@@ -134,15 +164,18 @@ def test_conv_unit_k_split_over_channel_slices(engine):
     assert torch.equal(outs[-1].float(), ref)
 
 
-def test_conv_unit_n_split_into_output_channel_slices(engine):
-    """64 -> 256 as two launches writing the two 128-channel halves of one output tensor (residual sliced alike)."""
+@pytest.mark.parametrize("n", [2, 8])  # 8 images of 28 pixels: the packed launch
+def test_conv_unit_n_split_into_output_channel_slices(engine, n):
+    """64 -> 256 as two launches writing the two 128-channel halves of one output tensor (residual sliced alike); the 64
+    input channels are the upper half of a 128-channel tensor."""
     import torch
     from aliby_amd import _lib
     from aliby_amd.extraction.engine import _ptr, _stream_ptr
 
     g = torch.Generator().manual_seed(12)
-    n, H, W, cin, ctot = 2, 28, 28, 64, 256
-    x = torch.randint(-1, 3, (n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
+    H, W, cin, ctot = 28, 28, 64, 256
+    wide = torch.randint(-1, 3, (n, H, W, 2 * cin), generator=g).to(torch.bfloat16).cuda()
+    x = wide[..., cin:].contiguous()
     w = (torch.randint(-1, 2, (ctot, cin, 3, 3), generator=g) * (torch.rand(ctot, cin, 3, 3, generator=g) < 0.15)).float().cuda()
     scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
     shift = torch.randint(-1, 2, (cin,), generator=g).float().cuda()
@@ -154,8 +187,8 @@ def test_conv_unit_n_split_into_output_channel_slices(engine):
         wpk = torch.empty(128 * cin * 9, dtype=torch.bfloat16, device="cuda")
         _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(wk), 128, cin, cin, _ptr(wpk), _stream_ptr()))
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
-            engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 0, _ptr(bias[n0:n0 + 128]), _ptr(res), 0,
-            n, H, W, cin, 128, 0, 0, 0, ctot, n0, 0, _stream_ptr()))
+            engine.ctx.handle, _ptr(wide), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 0, _ptr(bias[n0:n0 + 128]), _ptr(res), 0,
+            n, H, W, cin, 128, 0, 2 * cin, cin, ctot, n0, 0, _stream_ptr()))
     torch.cuda.synchronize()
     ref = _reference(x, w, scale, shift, bias, res, False, False)
     assert float(ref.abs().max()) <= 256
