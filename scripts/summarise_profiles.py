@@ -31,6 +31,22 @@ if files:
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             w.writerow([k, a[0], round(a[1] / 1e3, 1), round(a[1] / a[0] / 1e3, 2), round(a[2] / 1e3, 2), round(a[3] / 1e3, 2), round(100 * a[1] / tot, 2)])
     print("steady step: kernel time", tot / 1e6, "ms over", len(seg), "launches")
+    # GPU idle time between consecutive kernels of the step (dependent launches on one stream): how launch-bound the step is
+    end_so_far, idle, gaps = int(seg[0]["End_Timestamp"]), 0, []
+    for r in seg[1:]:
+        g = int(r["Start_Timestamp"]) - end_so_far
+        if g > 0:
+            idle += g
+            gaps.append(g)
+        end_so_far = max(end_so_far, int(r["End_Timestamp"]))
+    span = end_so_far - int(seg[0]["Start_Timestamp"])
+    gaps.sort()
+    json.dump({"step_span_ms": round(span / 1e6, 3), "kernel_busy_ms": round((span - idle) / 1e6, 3), "idle_ms": round(idle / 1e6, 3),
+               "launches": len(seg), "gaps": len(gaps), "median_gap_us": round(gaps[len(gaps) // 2] / 1e3, 2) if gaps else 0,
+               "p90_gap_us": round(gaps[int(len(gaps) * 0.9)] / 1e3, 2) if gaps else 0,
+               "idle_ms_in_gaps_over_20us": round(sum(g for g in gaps if g > 20000) / 1e6, 3),
+               "note": "rocprofv3 --kernel-trace timestamps; tracing itself slows the host's launch rate"},
+              open(f"profiles/{tag}_launch_gaps.json", "w"), indent=1)
     # the bench's timing groups, from the same trace: what `roofline.avg_launch_ms` / `roofline_mfma.avg_launch_ms` must agree with
     def grp(k):
         if k.startswith("k_conv3x3"):
