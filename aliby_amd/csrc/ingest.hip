@@ -438,6 +438,7 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
   if (dst_is_device) {
     ARG_CHECK(ctx, "a context is needed to upload");
     device = ctx->device;
+    HIP_TRY(hipSetDevice(device));  // the caller may be a helper thread that never selected the context's GPU
     if (stage.bytes < plane_bytes * n) {
       if (stage.p) HIP_TRY(hipHostFree(stage.p));
       stage = PinnedStage();

@@ -269,7 +269,7 @@ class LazyArray:
     def compute(self, **kwargs):
         return self[...]
 
-    def read_device(self, tp: int, ctx, stream_ptr, out=None):
+    def read_device(self, tp: int, ctx, stream_ptr, out=None, device=None):
         """View[tp] as a device tensor, decoded and uploaded by csrc/ingest.hip; None when the view's trailing two axes
         are not the source's plane axes (then `self[tp]` + a plain upload is the way)."""
         import torch
@@ -287,7 +287,9 @@ class LazyArray:
         ids = ids.transpose([a for a in self.dropped if a < nd - 2] + grid_axes)
         shape = self.shape[1:]
         if out is None:
-            out = torch.empty(shape, dtype=getattr(torch, src.dtype.name), device="cuda")
+            # (an explicit device: a helper thread's current device is not the rank's)
+            out = torch.empty(shape, dtype=getattr(torch, src.dtype.name),
+                              device=torch.device("cuda", torch.cuda.current_device() if device is None else device))
         src.decode(ids.ravel().tolist(), out.data_ptr(), dst_is_device=True, ctx=ctx, stream=stream_ptr)
         return out
 

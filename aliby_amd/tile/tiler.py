@@ -216,7 +216,7 @@ class Tiler:
 
             self._ingest_stream = torch.cuda.Stream()
             self._ingest_pool = ThreadPoolExecutor(max_workers=1)
-        ctx, stream = self._engine.ctx.handle, self._ingest_stream.cuda_stream
+        ctx, stream, device = self._engine.ctx.handle, self._ingest_stream.cuda_stream, torch.cuda.current_device()
         pending, self._ingest_pending = self._ingest_pending, None
         dev = None
         if pending is not None:
@@ -224,9 +224,9 @@ class Tiler:
             if pending[0] == tp:
                 dev = got
         if dev is None:
-            dev = pixels.read_device(tp, ctx, stream)
+            dev = pixels.read_device(tp, ctx, stream, None, device)
         if dev is not None and tp + 1 < pixels.shape[0]:
-            self._ingest_pending = (tp + 1, self._ingest_pool.submit(pixels.read_device, tp + 1, ctx, stream))
+            self._ingest_pending = (tp + 1, self._ingest_pool.submit(pixels.read_device, tp + 1, ctx, stream, None, device))
         return dev
 
     def rects(self, tp: int) -> np.ndarray:
