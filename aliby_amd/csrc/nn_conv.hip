@@ -186,7 +186,7 @@ struct ConvCfg {
   // when the image height is a multiple of the taller tile
   // (packed launches: 14-row tiles — 28, 56 and 112 are multiples of 14 — so a 28-row level is 504 tiles for the chip's 512
   // workgroup slots and the halo is 2 rows in 16)
-  static constexpr int PASSES = PACK ? 7 : ((CIN >= 64 && COUT >= 64) ? 2 : 1) * (TALL ? 2 : 1);
+  static constexpr int PASSES = (PACK && COUT >= 128) ? 7 : ((CIN >= 64 && COUT >= 64) ? 2 : 1) * (TALL ? 2 : 1);
   static constexpr int RG = 4 / NCB;                               // row groups per workgroup (4 waves)
   // PACK: one more window column, the zero column that separates two images meeting inside the 32-pixel block
   static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2 + (PACK ? 1 : 0);
@@ -197,7 +197,7 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = NPL * PLANE * 16;
   static constexpr int PIX_PER_IT = 256 / NPL;
   static constexpr int ITERS = (RAW + PIX_PER_IT - 1) / PIX_PER_IT;  // staging loads per thread and tile
-  static constexpr int BATCH = PACK ? (ITERS + 2) / 3 : (CIN >= 64 ? (ITERS + 1) / 2 : ITERS);  // staging loads in flight per thread
+  static constexpr int BATCH = (PACK && COUT >= 128) ? (ITERS + 2) / 3 : (CIN >= 64 ? (ITERS + 1) / 2 : ITERS);  // staging loads in flight per thread
   static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;  // pixel fragments in flight LDS -> VGPR ahead of their MFMAs
   static constexpr int DEPTH_POOL = (CIN >= 64 && COUT >= 64) ? 3 : 6;  // the pooling epilogue needs a few registers more
 };
@@ -663,9 +663,9 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // 32->32 at 224 rows +3..7 %: the fixed per-tile latency chain is amortised over twice the pixels)
   constexpr bool CAN_TALL = (CIN >= 64 && COUT >= 128) || (CIN == 32 && COUT == 32);
   // images narrower than the 224-pixel level-0 tile are packed side by side so that no MFMA column runs empty
-  if constexpr (!UP && COUT >= 128) {
-    static const bool pack_on = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) != 0 : true; }();
-    if (pack_on && !a.pin && (a.W == 28 || a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0 &&
+  if constexpr (!UP && COUT >= 64) {
+    static const int pack_on = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) : 3; }();  // bit 0: 128-cout shapes, bit 1: 64-cout
+    if ((pack_on & (COUT >= 128 ? 1 : 2)) && !a.pin && (a.W == 28 || a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0 &&
         a.H % ConvCfg<CIN, COUT, false, true>::TH == 0)
       return launch_conv_reg<CIN, COUT, UP, false, true>(ctx, a, stream);
   }

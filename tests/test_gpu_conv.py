@@ -81,15 +81,15 @@ def test_conv_unit_exact_on_integer_data(engine, cin, cout, in_up, shape):
 @pytest.mark.parametrize("shape", [(8, 28, 28), (16, 28, 28), (4, 56, 56), (8, 56, 56), (2, 112, 112), (4, 112, 112),
                                    (3, 56, 56), (7, 28, 28)])  # the last two: not a whole group, plain launch
 @pytest.mark.parametrize("res_up", [False, True])
-def test_conv_unit_packed_deep_level_images(engine, shape, res_up):
-    """64 -> 128 on 28 / 56 / 112-pixel images: G = 224 / W images share a tile row, blocks straddle two images
-    (per-image style shift, residual, store and pooled output on either side of the seam)."""
+@pytest.mark.parametrize("cin,cout", [(64, 128), (64, 64), (32, 64)])
+def test_conv_unit_packed_deep_level_images(engine, shape, res_up, cin, cout):
+    """28 / 56 / 112-pixel images: G = 224 / W images share a tile row, blocks straddle two images (per-image style
+    shift, residual, store and pooled output on either side of the seam)."""
     import torch
 
     torch.backends.cudnn.allow_tf32 = False
     n, H, W = shape
-    cin, cout = 64, 128
-    g = torch.Generator().manual_seed(n * 1000 + W)
+    g = torch.Generator().manual_seed(n * 1000 + W + cin)
     x = torch.randint(-1, 3, (n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
     w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
     scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
