@@ -255,3 +255,31 @@ def test_positions_for_rank_partition():
     for world in (1, 2, 4, 8):
         got = sorted(p for r in range(world) for p in positions_for_rank(37, r, world))
         assert got == list(range(37))
+
+
+# ---------------------------------------------------------------------------------- the boundary from plain C
+def build_c_demo(tmp_path):
+    import subprocess
+
+    root = Path(__file__).resolve().parents[1]
+    exe = tmp_path / "c_abi_demo"
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-I", str(root / "include"), str(root / "examples" / "c_abi_demo.c"), "-o", str(exe),
+           "-L", str(root / "aliby_amd"), "-laliby_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{root / 'aliby_amd'}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_c_caller_links_against_the_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/aliby_hip.h is a C header and the library a C ABI: a C11 program compiles against it with -Wall -Werror,
+    decodes a TIFF header through it (host code) and gets a loud error, not a fallback, when no GPU is visible."""
+    import subprocess
+
+    import torch
+
+    exe = build_c_demo(tmp_path)
+    tif = Path(__file__).parent / "golden" / "tiff" / "pil_lzw.tif"
+    out = subprocess.run([str(exe), str(tif)], capture_output=True, text=True, timeout=120)
+    assert "abi 1" in out.stdout and "tiff pages=1 width=52 height=40 bits=16 compression=5" in out.stdout
+    if not torch.cuda.is_available():
+        assert out.returncode == 0 and "no context:" in out.stdout

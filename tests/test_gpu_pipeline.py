@@ -331,3 +331,14 @@ def test_drift_on_device_matches_fixture_and_moves_the_tiles(engine):
     assert tiler.tile_locs.drifts == [[0.0, 0.0], [-2.0, 3.0], [-2.0, 3.0]]
     # drift-corrected tiles show the same piece of the sample at every timepoint
     assert all(np.array_equal(crops[0], c) for c in crops[1:])
+
+
+def test_c_caller_runs_the_stager_without_python(tmp_path, engine):
+    """examples/c_abi_demo.c: stage, crop with median padding and max-project Z from a plain C program."""
+    import subprocess
+
+    from tests.test_cpu_host import build_c_demo
+
+    out = subprocess.run([str(build_c_demo(tmp_path))], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "tile0[0,0]=210 (expect 210)" in out.stdout and out.stdout.strip().endswith("ok")
