@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="informational: no per-kernel HIP events, so the network forward "
                     "runs as a replayed hipGraph (the product path); the line then carries no roofline objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="experiment: dynamics + features of step k on a second stream while the "
+                    "network of step k+1 runs (software pipelining across steps)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -167,6 +169,37 @@ def main():
 
     step.parity = 0
 
+    # ---- experiment (--overlap): the step cut in two phases on two streams ------------------------------------------
+    post_stream = torch.cuda.Stream() if args.overlap else None
+    tiles2 = [tiles, torch.empty_like(tiles)] if args.overlap else None
+
+    def phase_net(buf):
+        tb = tiles2[buf]
+        with eng.timed("stage_crop_pad"):
+            _lib.check(eng.lib.aliby_crop_pad_u16(eng.ctx.handle, _ptr(stacks), B * C, Z, Y, X, _ptr(rect), 1, Y, X,
+                                                  _ptr(tb), _ptr(flags), _stream_ptr()))
+        px = tb.view(B, C, Z, Y, X)
+        plane = model.select_and_project(px, 0)
+        model.run_network(plane)  # output discarded, as in step(): the cost is what is measured
+        ev = torch.cuda.Event()
+        ev.record()
+        return px, plane, ev
+
+    def phase_post(state):
+        from aliby_amd.segment import dynamics
+
+        px, plane, ev = state
+        with torch.cuda.stream(post_stream):
+            post_stream.wait_event(ev)
+            labels, counts = dynamics.masks_from_flows(eng, dP_true, prob_true, niter=200, cellprob_threshold=0.0, flow_threshold=0.4,
+                                                       min_size=15, max_size_fraction=0.4)
+            planes = (px, _lib.U16)
+            m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
+            m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+            pending = eng.to_host_async((m1, m2), slot=step.parity)
+            step.parity ^= 1
+        return pending, table, counts
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -185,11 +218,20 @@ def main():
     barrier()
     t0 = time.perf_counter()
     pending = None
-    for _ in range(args.steps):
-        nxt, table, counts = step()
-        if pending is not None:
-            pending.wait()  # the previous step's rows are on the host (its buffers may be reused two steps later)
-        pending = nxt
+    if args.overlap:
+        state = phase_net(0)
+        for k in range(args.steps):
+            nxt_state = phase_net((k + 1) & 1) if k + 1 < args.steps else None  # queue the next network before this step's host read-backs
+            nxt, table, counts = phase_post(state)
+            if pending is not None:
+                pending.wait()
+            pending, state = nxt, nxt_state
+    else:
+        for _ in range(args.steps):
+            nxt, table, counts = step()
+            if pending is not None:
+                pending.wait()  # the previous step's rows are on the host (its buffers may be reused two steps later)
+            pending = nxt
     rows = tuple(torch.from_numpy(a) for a in pending.wait())  # the last step's rows land inside the timed region too
     barrier()
     dt = time.perf_counter() - t0
