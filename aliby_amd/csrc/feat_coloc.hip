@@ -244,6 +244,228 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
 
 
 // -----------------------------------------------------------------------------------------------------
+// All channel pairs of an object in one workgroup: the pixels of every channel in use are gathered once, then each
+// wave takes pairs in turn and runs the statistics above with wave-level reductions (shuffles, no barriers) — the
+// per-pair kernel is a chain of ~40 dependent reductions over a few hundred pixels, i.e. latency, and ten of them per
+// object ran as ten launches.  Same arithmetic per pair; sums are folded in wave order instead of block order.
+// -----------------------------------------------------------------------------------------------------
+#define COLOC_MAX_CH 8
+#define COLOC_MAX_PAIRS 28
+struct PairsArgs {
+  const u16* labels;
+  const void* planes;
+  int F, C, Y, X;
+  const aliby_object* tab;
+  int n_obj, cap;
+  double* out;
+  int ld;
+  double thr, scale_max;
+  const unsigned int* ranks;
+  const int* rmax;
+  int nch, npairs, any_rwc;
+  int chan[COLOC_MAX_CH];
+  int pair[COLOC_MAX_PAIRS][6];  // local channel a, local channel b, col_pearson, col_manders, col_rwc, col_costes
+};
+
+template <int K>
+__device__ __forceinline__ void wave_sum_all(double (&v)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = __shfl(wave_sum(v[k]), 0, 64);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_coloc_pairs(PairsArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ int wsum[4];
+  float* vals = reinterpret_cast<float*>(lds_raw);                                // [nch][cap]
+  unsigned int* rks = reinterpret_cast<unsigned int*>(vals + (size_t)a.nch * a.cap);  // [nch][cap] when any pair wants rwc
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t plane = (size_t)a.Y * a.X;
+
+  for (int oi = blockIdx.x; oi < a.n_obj; oi += gridDim.x) {
+    const aliby_object o = a.tab[oi];
+    double* out = a.out + (size_t)oi * a.ld;
+    if (o.area <= 0) {
+      for (int p = tid; p < a.npairs; p += blockDim.x)
+        for (int k = 2; k < 6; ++k)
+          if (a.pair[p][k] >= 0) { out[a.pair[p][k]] = NAN; out[a.pair[p][k] + 1] = NAN; }
+      continue;
+    }
+    const u16* lab = a.labels + (size_t)o.tile * plane;
+    const T* img = reinterpret_cast<const T*>(a.planes) + (size_t)o.tile * a.C * plane;
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, npix = h * w;
+    const u16 L = (u16)o.label;
+    __syncthreads();  // the previous object's pairs are done with the lists
+    int base = 0;
+    for (int i0 = 0; i0 < npix; i0 += blockDim.x) {
+      const int i = i0 + tid;
+      bool in = false;
+      size_t idx = 0;
+      if (i < npix) {
+        idx = (size_t)(o.y0 + i / w) * a.X + (o.x0 + i % w);
+        in = lab[idx] == L;
+      }
+      const int pos = block_compact_slot(in, base, wsum);
+      if (in) {
+        for (int c = 0; c < a.nch; ++c) {
+          vals[(size_t)c * a.cap + pos] = px_load<T>(img + (size_t)a.chan[c] * plane, idx);
+          if (a.any_rwc) rks[(size_t)c * a.cap + pos] = a.ranks[((size_t)o.tile * a.C + a.chan[c]) * plane + idx];
+        }
+      }
+    }
+    __syncthreads();
+    const int N = base;
+    const double dN = (double)N;
+
+    for (int p = wave; p < a.npairs; p += 4) {
+      const int ca = a.pair[p][0], cb = a.pair[p][1];
+      const int col_pearson = a.pair[p][2], col_manders = a.pair[p][3], col_rwc = a.pair[p][4], col_costes = a.pair[p][5];
+      const float* fv = vals + (size_t)ca * a.cap;
+      const float* sv = vals + (size_t)cb * a.cap;
+      const unsigned int* rk1 = rks + (size_t)ca * a.cap;
+      const unsigned int* rk2 = rks + (size_t)cb * a.cap;
+
+      double s2[2] = {0, 0};
+      float m1 = -INFINITY, m2 = -INFINITY;
+      for (int j = lane; j < N; j += 64) {
+        s2[0] += (double)fv[j]; s2[1] += (double)sv[j];
+        m1 = fmaxf(m1, fv[j]); m2 = fmaxf(m2, sv[j]);
+      }
+      wave_sum_all<2>(s2);
+      const double mean1 = s2[0] / dN, mean2 = s2[1] / dN;
+      const float MAX1 = __shfl(wave_max(m1), 0, 64), MAX2 = __shfl(wave_max(m2), 0, 64);
+
+      if (col_pearson >= 0) {
+        double q[3] = {0, 0, 0};
+        for (int j = lane; j < N; j += 64) {
+          const double x = (double)fv[j] - mean1, y = (double)sv[j] - mean2;
+          q[0] += x * x; q[1] += y * y; q[2] += x * y;
+        }
+        wave_sum_all<3>(q);
+        if (lane == 0) {
+          out[col_pearson] = q[2] / (sqrt(q[0]) * sqrt(q[1]));
+          out[col_pearson + 1] = q[2] / q[0];
+        }
+      }
+
+      const double tff = (a.thr / 100.0) * (double)MAX1, tss = (a.thr / 100.0) * (double)MAX2;
+      double tot1 = 0, tot2 = 0;
+      int any_comb = 0;
+      if (col_manders >= 0 || col_rwc >= 0) {
+        double q[4] = {0, 0, 0, 0};
+        int anyc = 0;
+        for (int j = lane; j < N; j += 64) {
+          const double f = fv[j], s = sv[j];
+          const bool a1 = f >= tff, a2 = s >= tss;
+          if (a1) q[0] += f;
+          if (a2) q[1] += s;
+          if (a1 && a2) { q[2] += f; q[3] += s; anyc = 1; }
+        }
+        wave_sum_all<4>(q);
+        any_comb = __shfl(wave_max(anyc), 0, 64);
+        tot1 = q[0]; tot2 = q[1];
+        if (col_manders >= 0 && lane == 0) {
+          out[col_manders] = any_comb ? q[2] / tot1 : 0.0;
+          out[col_manders + 1] = any_comb ? q[3] / tot2 : 0.0;
+        }
+      }
+
+      if (col_rwc >= 0) {
+        const double R = (double)(max(a.rmax[(size_t)oi * a.C + a.chan[ca]], a.rmax[(size_t)oi * a.C + a.chan[cb]]) + 1);
+        double q[2] = {0, 0};
+        for (int j = lane; j < N; j += 64) {
+          const double f = fv[j], s = sv[j];
+          if (f >= tff && s >= tss) {
+            const long long di = llabs((long long)rk1[j] - (long long)rk2[j]);
+            const double wgt = (R - (double)di) * 1.0 / R;
+            q[0] += f * wgt; q[1] += s * wgt;
+          }
+        }
+        wave_sum_all<2>(q);
+        if (lane == 0) {
+          out[col_rwc] = any_comb ? q[0] / tot1 : 0.0;
+          out[col_rwc + 1] = any_comb ? q[1] / tot2 : 0.0;
+        }
+      }
+
+      if (col_costes >= 0) {
+        double q[3] = {0, 0, 0};
+        for (int j = lane; j < N; j += 64) {
+          const double f = fv[j], s = sv[j];
+          if (f > 0 || s > 0) { q[0] += 1; q[1] += f; q[2] += s; }
+        }
+        wave_sum_all<3>(q);
+        const double nnz = q[0], xmean = q[1] / nnz, ymean = q[2] / nnz, zmean = (q[1] + q[2]) / nnz;
+        double v3[3] = {0, 0, 0};
+        for (int j = lane; j < N; j += 64) {
+          const double f = fv[j], s = sv[j];
+          if (f > 0 || s > 0) {
+            const double dx = f - xmean, dy = s - ymean, dz = (f + s) - zmean;
+            v3[0] += dx * dx; v3[1] += dy * dy; v3[2] += dz * dz;
+          }
+        }
+        wave_sum_all<3>(v3);
+        const double xvar = v3[0] / (nnz - 1), yvar = v3[1] / (nnz - 1), zvar = v3[2] / (nnz - 1);
+        const double covar = 0.5 * (zvar - (xvar + yvar));
+        const double denom = 2 * covar;
+        const double num = (yvar - xvar) + sqrt((yvar - xvar) * (yvar - xvar) + 4 * (covar * covar));
+        const double cA = num / denom, cB = ymean - cA * xmean;
+        double left = 1, right = a.scale_max;
+        double mid = floor((right - left) / (6.0 / 5.0)) + left;
+        double lastmid = 0, valid = 1;
+        for (int it = 0; it < 200 && lastmid != mid; ++it) {
+          const double t1 = mid / a.scale_max, t2 = cA * t1 + cB;
+          double c3[3] = {0, 0, 0};
+          for (int j = lane; j < N; j += 64) {
+            const double f = fv[j], s = sv[j];
+            if (f < t1 || s < t2) { c3[0] += 1; c3[1] += f; c3[2] += s; }
+          }
+          wave_sum_all<3>(c3);
+          if (c3[0] <= 2) {
+            left = mid - 1;
+          } else {
+            const double mx = c3[1] / c3[0], my = c3[2] / c3[0];
+            double p3[3] = {0, 0, 0};
+            for (int j = lane; j < N; j += 64) {
+              const double f = fv[j], s = sv[j];
+              if (f < t1 || s < t2) { const double dx = f - mx, dy = s - my; p3[0] += dx * dx; p3[1] += dy * dy; p3[2] += dx * dy; }
+            }
+            wave_sum_all<3>(p3);
+            const double nx = sqrt(p3[0]), ny = sqrt(p3[1]);
+            double r = NAN;
+            if (nx != 0 && ny != 0) r = fmax(fmin(p3[2] / (nx * ny), 1.0), -1.0);
+            if (r < 0) left = mid - 1;
+            else if (r >= 0) { right = mid + 1; valid = mid; }
+          }
+          lastmid = mid;
+          if (right - left > 6) mid = floor((right - left) / (6.0 / 5.0)) + left;
+          else mid = floor((right - left) / 2.0) + left;
+        }
+        const double t1 = (valid - 1) / a.scale_max, t2 = cA * t1 + cB;
+        double c4[4] = {0, 0, 0, 0};
+        int f_any = 0, s_any = 0, c_any = 0;
+        for (int j = lane; j < N; j += 64) {
+          const double f = fv[j], s = sv[j];
+          const bool fa = f > t1, sa = s > t2;
+          f_any |= fa; s_any |= sa;
+          if (f >= t1) c4[0] += f;
+          if (s >= t2) c4[1] += s;
+          if (fa && sa) { c4[2] += f; c4[3] += s; c_any = 1; }
+        }
+        wave_sum_all<4>(c4);
+        const int FA = __shfl(wave_max(f_any), 0, 64), SA = __shfl(wave_max(s_any), 0, 64), CA = __shfl(wave_max(c_any), 0, 64);
+        if (lane == 0) {
+          const double d1 = FA ? c4[0] : 0.0, d2 = SA ? c4[1] : 0.0;
+          out[col_costes] = CA ? c4[2] / d1 : 0.0;
+          out[col_costes + 1] = CA ? c4[3] / d2 : 0.0;
+        }
+      }
+    }
+  }
+}
+
+
+// -----------------------------------------------------------------------------------------------------
 // dense per-object ranks of one channel: rank(p) = number of distinct values of the object smaller than
 // the value at p (CellProfiler's Rank_im: lexsort + cumsum of "value changed").  One sort per
 // (object, channel), written into a tile-shaped plane so that every channel pair reuses it.
@@ -422,6 +644,65 @@ extern "C" int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, cons
     dim3 grid(g), block(256);
     if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_coloc<u16, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_coloc<float, true>), grid, block, 0, s, a);
+  }
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+// pairs_host: n_pairs x 6 ints (ch0, ch1, col_pearson, col_manders, col_rwc, col_costes; a column of -1 skips the metric).
+// Returns ALIBY_ERR_TOO_LARGE without launching when the objects' pixel lists of all channels do not fit the LDS budget
+// (the caller then uses aliby_features_coloc pair by pair).
+extern "C" int aliby_features_coloc_pairs(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
+                                          int Y, int X, const int32_t* pairs_host, int n_pairs,
+                                          const aliby_object* table_dev, int n_obj, int max_area, double* out, int ld,
+                                          double thr_percent, double costes_scale_max, const uint32_t* ranks_dev,
+                                          const int32_t* rmax_dev, void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (n_obj == 0 || n_pairs == 0) return ALIBY_OK;
+  ARG_CHECK(labels && planes && table_dev && out && pairs_host, "NULL argument");
+  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
+  ARG_CHECK(F > 0 && Y > 0 && X > 0 && max_area >= 0, "bad shape");
+  ARG_CHECK(n_pairs > 0 && n_pairs <= COLOC_MAX_PAIRS, "too many channel pairs for one launch");
+  PairsArgs a;
+  a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.tab = table_dev; a.n_obj = n_obj;
+  a.out = out; a.ld = ld; a.thr = thr_percent; a.scale_max = costes_scale_max; a.ranks = ranks_dev; a.rmax = rmax_dev;
+  a.nch = 0; a.npairs = n_pairs; a.any_rwc = 0;
+  for (int p = 0; p < n_pairs; ++p) {
+    const int32_t* q = pairs_host + 6 * p;
+    for (int k = 0; k < 2; ++k) {
+      ARG_CHECK(q[k] >= 0 && q[k] < C, "channel out of range");
+      int loc = -1;
+      for (int c = 0; c < a.nch; ++c) if (a.chan[c] == q[k]) loc = c;
+      if (loc < 0) {
+        ARG_CHECK(a.nch < COLOC_MAX_CH, "too many distinct channels for one launch");
+        loc = a.nch;
+        a.chan[a.nch++] = q[k];
+      }
+      a.pair[p][k] = loc;
+    }
+    for (int k = 2; k < 6; ++k) {
+      ARG_CHECK(q[k] < 0 || q[k] + 2 <= ld, "columns exceed row stride");
+      a.pair[p][k] = q[k];
+    }
+    if (q[4] >= 0) a.any_rwc = 1;
+  }
+  ARG_CHECK(!a.any_rwc || (ranks_dev && rmax_dev), "rwc needs the rank planes (aliby_object_ranks)");
+  int cap = 64;
+  while (cap < max_area) cap <<= 1;
+  a.cap = cap;
+  const size_t need = (size_t)a.nch * cap * 4 * (a.any_rwc ? 2 : 1);
+  if (need > 144 * 1024) {
+    aliby_set_error("coloc_pairs: %zu bytes of pixel lists per object exceed the LDS budget", need);
+    return ALIBY_ERR_TOO_LARGE;
+  }
+  hipStream_t s = as_stream(stream);
+  dim3 grid(n_obj), block(256);
+  if (dtype == ALIBY_U16) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_coloc_pairs<u16>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    hipLaunchKernelGGL((k_coloc_pairs<u16>), grid, block, need, s, a);
+  } else {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_coloc_pairs<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    hipLaunchKernelGGL((k_coloc_pairs<float>), grid, block, need, s, a);
   }
   KERNEL_CHECK();
   return ALIBY_OK;

@@ -392,6 +392,34 @@ class FeatureEngine:
             e["done"].add(ch)
         return e["ranks"], e["rmax"]
 
+    def coloc_pairs(self, labels, planes, dtype, pairs, table: ObjectTable, out, thr=15.0, scale_max=255.0) -> bool:
+        """All channel pairs in one launch (aliby_features_coloc_pairs).  pairs = [((ch0, ch1), cols), ...] with cols as in
+        `coloc`.  False (nothing launched) when the objects' pixel lists do not fit the kernel's LDS budget or there are more
+        pairs / channels than one launch takes: the caller then goes pair by pair."""
+        F, Cn, Y, X = planes.shape
+        chans = sorted({c for (pair, _) in pairs for c in pair})
+        any_rwc = any(cols.get("rwc") is not None for _, cols in pairs)
+        cap = 64
+        while cap < table.max_area:
+            cap <<= 1
+        if len(pairs) > 28 or len(chans) > 8 or len(chans) * cap * 4 * (2 if any_rwc else 1) > 144 * 1024:
+            return False
+        ranks = rmax = None
+        if any_rwc:
+            ranks, rmax = self.rank_planes(labels, planes, dtype, table, tuple(chans))
+        c = lambda cols, k: -1 if cols.get(k) is None else int(cols[k])  # noqa: E731
+        spec = np.asarray([[ch0, ch1, c(cols, "pearson"), c(cols, "manders_fold"), c(cols, "rwc"), c(cols, "costes")]
+                           for (ch0, ch1), cols in pairs], dtype=np.int32)
+        with self.timed("coloc"):
+            _lib.check(
+                self.lib.aliby_features_coloc_pairs(
+                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, spec.ctypes.data, len(pairs), _ptr(table.dev),
+                    table.n_obj, table.max_area, _ptr(out), out.stride(0), float(thr), float(scale_max),
+                    _ptr(ranks) if ranks is not None else 0, _ptr(rmax) if rmax is not None else 0, _stream_ptr(),
+                )
+            )
+        return True
+
     def coloc(self, labels, planes, dtype, ch0, ch1, table: ObjectTable, out, cols, thr=15.0, scale_max=255.0):
         """cols = dict(pearson=col|None, manders_fold=..., rwc=..., costes=...)."""
         F, Cn, Y, X = planes.shape

@@ -230,12 +230,25 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
             plane, dt = cache.get(red_z)
             if "rwc" in g["cols"]:
                 eng.rank_planes(labels, plane, dt, table, (ch0, ch1))
-        fan.fork()
+        # every pair that shares a z-reduction and its parameters goes into one launch (csrc/feat_coloc.hip, k_coloc_pairs)
+        import os
+
+        batches = {}
         for ((ch0, ch1), red_z), g in groups.items():
+            batches.setdefault((red_z, g["thr"], g["scale_max"]), []).append(((ch0, ch1), g["cols"]))
+        left = []
+        for (red_z, thr, scale_max), pairs in batches.items():
             plane, dt = cache.get(red_z)
-            with fan.next_stream():
-                eng.coloc(labels, plane, dt, ch0, ch1, table, out, g["cols"], thr=g["thr"], scale_max=g["scale_max"])
-        fan.join()
+            if os.environ.get("ALIBY_COLOC_PAIRS", "1") == "0" or len(pairs) < 2 or not eng.coloc_pairs(
+                    labels, plane, dt, pairs, table, out, thr=thr, scale_max=scale_max):
+                left.extend((pair, red_z, cols, thr, scale_max) for pair, cols in pairs)
+        if left:
+            fan.fork()
+            for (ch0, ch1), red_z, cols, thr, scale_max in left:
+                plane, dt = cache.get(red_z)
+                with fan.next_stream():
+                    eng.coloc(labels, plane, dt, ch0, ch1, table, out, cols, thr=thr, scale_max=scale_max)
+            fan.join()
         return out, blocks
 
     # shared, pixel-independent inputs first, on the main stream (each is cached on the object table)

@@ -322,6 +322,16 @@ int aliby_features_coloc(aliby_ctx* ctx, const uint16_t* labels, const void* pla
                          double* out, int ld, int col_pearson, int col_manders, int col_rwc,
                          int col_costes, double thr_percent, double costes_scale_max,
                          const uint32_t* ranks_dev, const int32_t* rmax_dev, void* stream);
+/* The same metrics for a list of channel pairs in ONE launch: an object's pixels of every channel in use are gathered
+ * once and each wave of its workgroup takes pairs in turn (the builder's multi tree is C(5,2) = 10 pairs x 4 metrics,
+ * pipe_builder.py:33-43).  pairs_host: n_pairs x 6 ints (ch0, ch1, col_pearson, col_manders, col_rwc, col_costes; -1
+ * skips a metric).  Returns ALIBY_ERR_TOO_LARGE, without launching, when the pixel lists exceed the LDS budget: the
+ * caller then goes pair by pair through aliby_features_coloc. */
+int aliby_features_coloc_pairs(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
+                               int Y, int X, const int32_t* pairs_host, int n_pairs, const aliby_object* table_dev,
+                               int n_obj, int max_area, double* out, int ld, double thr_percent,
+                               double costes_scale_max, const uint32_t* ranks_dev, const int32_t* rmax_dev,
+                               void* stream);
 /* Dense per-object ranks of one channel (CellProfiler's Rank_im of the RWC coefficient): ranks_dev
  * [F,C,Y,X] uint32 receives, at every object pixel, the number of distinct smaller values of that object in
  * `channel`; rmax_dev [n_obj, C] the largest rank.  One sort per (object, channel), shared by all pairs. */

@@ -104,11 +104,19 @@ def test_coloc_matches_oracle(engine, objset, mode):
     dl = to_device_u16(labels[None])
     dp, dt = to_device_planes(planes[None])
     tab = engine.object_table(dl)
-    for c0, c1 in combinations(range(3), 2):
+    # the same metrics through the all-pairs launch (one workgroup per object, a wave per pair)
+    pair_list = list(combinations(range(3), 2))
+    allout = engine.new_output(tab.n_obj, 8 * len(pair_list))
+    assert engine.coloc_pairs(dl, dp, dt, [(pr, dict(pearson=8 * i, manders_fold=8 * i + 2, rwc=8 * i + 4, costes=8 * i + 6))
+                                           for i, pr in enumerate(pair_list)], tab, allout)
+    torch.cuda.synchronize()
+    allgot = allout.cpu().numpy()
+    for pi, (c0, c1) in enumerate(pair_list):
         out = engine.new_output(tab.n_obj, 8)
         engine.coloc(dl, dp, dt, c0, c1, tab, out, dict(pearson=0, manders_fold=2, rwc=4, costes=6))
         torch.cuda.synchronize()
         got = out.cpu().numpy()
+        assert np.allclose(allgot[:, 8 * pi: 8 * pi + 8], got, rtol=1e-9, atol=1e-12, equal_nan=True)
         # the reference evaluates one full-frame binary mask per object (extract.py:222-226); RWC's
         # ranks and Costes' threshold are per call, so the oracle is driven the same way
         ref = {}
@@ -120,6 +128,17 @@ def test_coloc_matches_oracle(engine, objset, mode):
         names = ["Correlation_Pearson", "Correlation_Slope", "Correlation_Manders_1", "Correlation_Manders_2",
                  "Correlation_RWC_1", "Correlation_RWC_2", "Correlation_Costes_1", "Correlation_Costes_2"]
         _compare(names, got, ref)
+        _compare(names, allgot[:, 8 * pi: 8 * pi + 8], ref)
+    # a subset of metrics, and the refusal when the pixel lists would not fit the kernel's LDS budget
+    part = engine.new_output(tab.n_obj, 4)
+    assert engine.coloc_pairs(dl, dp, dt, [((0, 2), dict(pearson=0)), ((1, 2), dict(costes=2))], tab, part)
+    torch.cuda.synchronize()
+    assert np.allclose(part.cpu().numpy()[:, :2], allgot[:, 8:10], rtol=1e-9, equal_nan=True)
+    assert np.allclose(part.cpu().numpy()[:, 2:], allgot[:, 22:24], rtol=1e-9, equal_nan=True)
+    big = type(tab).__new__(type(tab))
+    big.__dict__.update(tab.__dict__)
+    big.max_area = 1 << 16
+    assert engine.coloc_pairs(dl, dp, dt, [((0, 1), dict(pearson=0)), ((0, 2), dict(pearson=2))], big, part) is False
 
 
 @pytest.mark.parametrize("objset", ["nuclei", "cells"])
