@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
 // weights.  Two LDS images per workgroup: R (raw bf16 window, pixel-major = lane-linear, as the DMA
 // writes it) and A (the activated channel-octet planes the MFMA loop reads).  Per tile:
 //     wait DMA(t), barrier | prologue R -> A | barrier | seed accumulators | issue DMA(t+1) | MFMA | store
-template <int CIN, int COUT, bool UP>
+template <int CIN, int COUT, bool UP, bool PACK = false>
 struct DmaCfg {
   static constexpr int KC = CIN / 16, NPL = CIN / 8, NCB = COUT / 32;
   // (a CIN = 128 instantiation — 288 weight VGPRs, one wave per SIMD, two row passes — was measured at the same
@@ -433,7 +433,7 @@ struct DmaCfg {
   static constexpr int R = CIN >= 64 ? 2 : 4;      // output rows per wave and pass
   static constexpr int PASSES = (CIN >= 128 || COUT >= 128) ? 2 : 1;  // row passes per tile (accumulators reused): a taller tile, less halo
   static constexpr int RG = 4 / NCB;
-  static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2;
+  static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2 + (PACK ? 1 : 0);  // PACK: + the seam's zero column
   static constexpr int RAW = LH * LW;
   static constexpr int PLANE = NPL == 4 ? RAW + (10 - RAW % 8) % 8 : (RAW | 1);
   static constexpr int A_SLOTS = NPL * PLANE;
@@ -448,9 +448,11 @@ struct DmaCfg {
   static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;
 };
 
-template <int CIN, int COUT, bool UP>
-__global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void k_conv3x3_dma(ConvArgs a) {
-  using cfg = DmaCfg<CIN, COUT, UP>;
+// PACK (upsampled input only): the packed launch of k_conv3x3, with the raw half-resolution window switching images at the seam.
+template <int CIN, int COUT, bool UP, bool PACK = false>
+__global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP, PACK>::WAVES_PER_SIMD)) void k_conv3x3_dma(ConvArgs a) {
+  static_assert(!PACK || UP, "the packed LDS-DMA variant is written for upsampled input");
+  using cfg = DmaCfg<CIN, COUT, UP, PACK>;
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
   constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, RLW = cfg::RLW, PASSES = cfg::PASSES;
   constexpr int PIX_PER_IT = cfg::PIX_PER_IT, ITERS = cfg::ITERS, GIT = cfg::GIT;
@@ -485,7 +487,13 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
     const int ry0 = UP ? (ty * TH >> 1) - 1 : ty * TH - 1, rx0 = UP ? (tx * TW >> 1) - 1 : tx * TW - 1;
-    const uint4* inN = a.in + (size_t)n * IH * IW * a.cs + a.coff;
+    int g0 = 0, cst = 0, half = 1 << 20;
+    if constexpr (PACK) {
+      g0 = (tx * TW) / a.W;
+      cst = tx * TW - g0 * a.W;
+      half = (a.W - cst) >> 1;  // raw columns 0..half come from image g0 (left halo + its last columns), the rest from g0 + 1
+    }
+    const uint4* inN = a.in + (size_t)(PACK ? n * a.G : n) * IH * IW * a.cs + a.coff;
     int t0 = tid;
     asm volatile("" : "+v"(t0));
 #pragma unroll
@@ -493,8 +501,16 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       const int unit = t0 + k * 256;  // lane-linear: unit u lands at ldsR[u]
       const int rpix = unit / NPL, oct = unit % NPL;
       const int rly = rpix / RLW, rlx = rpix - rly * RLW;
-      const int iy = min(max(ry0 + rly, 0), IH - 1), ix = min(max(rx0 + rlx, 0), IW - 1);  // clamped: masked later
-      const uint4* g = inN + (unsigned)((iy * IW + ix) * a.cs + oct);
+      const int iy = min(max(ry0 + rly, 0), IH - 1);
+      int ix, img = 0;
+      if constexpr (PACK) {
+        const bool first = rlx <= half;
+        ix = min(max(first ? (cst >> 1) - 1 + rlx : rlx - half - 1, 0), IW - 1);
+        img = first ? g0 : min(g0 + 1, a.G - 1);
+      } else {
+        ix = min(max(rx0 + rlx, 0), IW - 1);  // clamped: masked later
+      }
+      const uint4* g = inN + (unsigned)(((img * IH + iy) * IW + ix) * a.cs + oct);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(ldsR + k * 256 + wave_u * 64), 16, 0, 0);
     }
@@ -507,14 +523,28 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
     const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
     const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    const int gx = x0 + px;
+    int g0 = 0, cst = x0, kb = 1 << 20, nimg = n;
+    if constexpr (PACK) {
+      g0 = x0 / a.W;
+      cst = x0 - g0 * a.W;
+      kb = a.W - cst;
+      nimg = n * a.G;
+    }
+    const int second = (PACK && px >= kb) ? 1 : 0;
+    const int gx = PACK ? (second ? px - kb : cst + px) : x0 + px;
+    const int irow = PACK ? (g0 + second) * a.H : 0;
 
     // ---- everything this tile needs from global memory besides the window: requested before the DMA wait
-    f32x2_t sh[4];
+    f32x2_t sh[4], sh1[PACK ? 4 : 1];
     {
-      const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
+      const float* sp = a.shift + (size_t)(nimg + g0) * a.shift_stride + pl * 8;
 #pragma unroll
       for (int k = 0; k < 4; ++k) sh[k] = f32x2_t{sp[2 * k], sp[2 * k + 1]};
+      if constexpr (PACK) {
+        const float* sq = a.shift + (size_t)(nimg + min(g0 + 1, a.G - 1)) * a.shift_stride + pl * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh1[k] = f32x2_t{sq[2 * k], sq[2 * k + 1]};
+      }
     }
     float4 b4[4] = {};
     if (a.bias) {
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       for (int q = 0; q < 4; ++q) b4[q] = bp[q];
     }
     uint4 rr[R][2];
-    auto load_res = [&](int pass) { conv_load_res<R>(a, n, 0, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
+    auto load_res = [&](int pass) { conv_load_res<R>(a, nimg, irow, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
     if (a.res) load_res(0);
     CONV_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
@@ -539,11 +569,29 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
         int lx = qx + (it * PIX_PER_IT) % LW, ly = qy + (it * PIX_PER_IT) / LW;
         if (lx >= LW) { lx -= LW; ly += 1; }
         const int gy = y0 - 1 + ly, gxi = x0 - 1 + lx;
-        const unsigned keep = 0u - (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W);
         const int pix = p0 + it * PIX_PER_IT;
-        // (the last round can run past the window: its raw index is clamped, its value never stored)
-        const int rpix = UP ? min(((gy >> 1) - ry0) * RLW + ((gxi >> 1) - rx0), cfg::RLH * RLW - 1) : min(pix, RAW - 1);
-        const uint4 o = conv_act8(ldsR[rpix * NPL + pl], sc, sh, keep);
+        unsigned keep;
+        int rpix;
+        uint4 o;
+        if constexpr (PACK) {
+          // window slot -> block pixel -1..32 (see k_conv3x3) -> (image, column) -> raw half-resolution column
+          const int gapi = kb < 32 ? kb + 1 : TW + 2;
+          const int bp = lx - 1 - (lx > gapi ? 1 : 0);
+          const int snd = bp >= kb ? 1 : 0;
+          const int c = snd ? bp - kb : cst + bp;
+          keep = 0u - (unsigned)(lx != gapi && c >= 0 && c < a.W && !(bp == TW && kb == TW) && (unsigned)gy < (unsigned)a.H);
+          const int rcol = snd ? (kb >> 1) + 1 + (c >> 1) : ((cst + bp) >> 1) - ((cst >> 1) - 1);
+          rpix = min(max(((gy >> 1) - ry0) * RLW + rcol, 0), cfg::RLH * RLW - 1);
+          f32x2_t shs[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) shs[k] = snd ? sh1[k] : sh[k];
+          o = conv_act8(ldsR[rpix * NPL + pl], sc, shs, keep);
+        } else {
+          keep = 0u - (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W);
+          // (the last round can run past the window: its raw index is clamped, its value never stored)
+          rpix = UP ? min(((gy >> 1) - ry0) * RLW + ((gxi >> 1) - rx0), cfg::RLH * RLW - 1) : min(pix, RAW - 1);
+          o = conv_act8(ldsR[rpix * NPL + pl], sc, sh, keep);
+        }
         if (it == ITERS - 1 && pix >= RAW) continue;
         ldsA[pl * PLANE + pix] = o;
       }
@@ -560,9 +608,9 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP>::WAVES_PER_SIMD)) void 
       if (pass + 1 < PASSES && a.res) load_res(pass + 1);                   // consumed after this pass's MFMA loop
       __builtin_amdgcn_sched_barrier(0);
       if (pass == 0) CONV_STAMP(4);
-      conv_mfma<R, KC, cfg::DEPTH, PLANE, LW>(reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px, wfrag, acc);
+      conv_mfma<R, KC, cfg::DEPTH, PLANE, LW>(reinterpret_cast<const bf16x8_t*>(ldsA) + hh * PLANE + rbase * LW + px + second, wfrag, acc);
       if (pass == PASSES - 1) CONV_STAMP(5);
-      conv_store<R>(a, n, 0, y0 + rbase, gx, c0, acc);
+      conv_store<R>(a, nimg, irow, y0 + rbase, gx, c0, acc);
     }
     CONV_STAMP(6);
   }
@@ -590,24 +638,25 @@ __global__ void k_pack_conv3x3(const float* w, int cout, int cin_src, int cin, i
 
 unsigned long long* g_conv_trace = nullptr;
 
-template <int CIN, int COUT, bool UP>
+template <int CIN, int COUT, bool UP, bool PACK = false>
 int launch_conv_dma(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
-  using cfg = DmaCfg<CIN, COUT, UP>;
-  a.tiles_x = (a.W + cfg::TW - 1) / cfg::TW;
+  using cfg = DmaCfg<CIN, COUT, UP, PACK>;
+  a.G = PACK ? 224 / a.W : 1;
+  a.tiles_x = PACK ? 224 / cfg::TW : (a.W + cfg::TW - 1) / cfg::TW;
   a.tiles_y = (a.H + cfg::TH - 1) / cfg::TH;
-  const long long nt = (long long)a.N * a.tiles_x * a.tiles_y;
+  const long long nt = (long long)(a.N / a.G) * a.tiles_x * a.tiles_y;
   ARG_CHECK(nt < INT_MAX, "conv3x3: too many tiles");
   a.ntiles = (int)nt;
   static bool attr_done = false;
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<CIN, COUT, UP>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<CIN, COUT, UP, PACK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
     attr_done = true;
   }
   const int per_xcd = (a.ntiles + 7) / 8;
   const int cap = 32 * cfg::WAVES_PER_SIMD;  // workgroups per XCD: 32 CUs x (1 or 2) resident workgroups
   const int nslots = per_xcd < cap ? per_xcd : cap;
-  hipLaunchKernelGGL((k_conv3x3_dma<CIN, COUT, UP>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((k_conv3x3_dma<CIN, COUT, UP, PACK>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   KERNEL_CHECK();
   return ALIBY_OK;
 }
@@ -658,13 +707,20 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
   // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
   static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
-  if (use_dma && !a.pool && !a.pin) return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);  // the pooled output is an epilogue of the register-staged variant
+  if (use_dma && !a.pool && !a.pin) {  // the pooled output is an epilogue of the register-staged variant
+    if constexpr (UP && COUT >= 64) {
+      static const int pack_up = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) : 7; }();  // bit 2: upsampled shapes
+      if ((pack_up & 4) && (a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0 && a.H % DmaCfg<CIN, COUT, UP, true>::TH == 0)
+        return launch_conv_dma<CIN, COUT, UP, true>(ctx, a, stream);
+    }
+    return launch_conv_dma<CIN, COUT, UP>(ctx, a, stream);
+  }
   // a taller tile where it divides the image and fits two workgroups per CU (measured: 64->128 at 56 rows +10 %,
   // 32->32 at 224 rows +3..7 %: the fixed per-tile latency chain is amortised over twice the pixels)
   constexpr bool CAN_TALL = (CIN >= 64 && COUT >= 128) || (CIN == 32 && COUT == 32);
   // images narrower than the 224-pixel level-0 tile are packed side by side so that no MFMA column runs empty
   if constexpr (!UP && COUT >= 64) {
-    static const int pack_on = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) : 3; }();  // bit 0: 128-cout shapes, bit 1: 64-cout
+    static const int pack_on = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) : 7; }();  // bit 0: 128-cout shapes, bit 1: 64-cout
     if ((pack_on & (COUT >= 128 ? 1 : 2)) && !a.pin && (a.W == 28 || a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0 &&
         a.H % ConvCfg<CIN, COUT, false, true>::TH == 0)
       return launch_conv_reg<CIN, COUT, UP, false, true>(ctx, a, stream);

@@ -108,6 +108,32 @@ def test_conv_unit_packed_deep_level_images(engine, shape, res_up, cin, cout):
     assert torch.equal(pool.float(), ref_pool)
 
 
+@pytest.mark.parametrize("shape", [(4, 56, 56), (8, 56, 56), (2, 112, 112), (6, 112, 112), (3, 56, 56)])
+@pytest.mark.parametrize("cout", [64, 128])
+@pytest.mark.parametrize("res_up", [False, True])
+def test_conv_unit_packed_with_upsampled_input(engine, shape, cout, res_up):
+    """The LDS-DMA variant's packed launch: the half-resolution raw window switches images at the seam."""
+    import torch
+
+    torch.backends.cudnn.allow_tf32 = False
+    n, H, W = shape
+    cin = 64
+    g = torch.Generator().manual_seed(n * 77 + W + cout)
+    x = torch.randint(-1, 3, (n, H // 2, W // 2, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.15)).float().cuda()
+    scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
+    rh, rw = (H // 2, W // 2) if res_up else (H, W)
+    res = torch.randint(-3, 4, (n, rh, rw, cout), generator=g).to(torch.bfloat16).cuda()
+    for sh in (shift, shift[0].contiguous()):
+        for r in (res, None):
+            out = _run(engine, x, w, scale, sh, bias, r, res_up, True, H, W)
+            ref = _reference(x, w, scale, sh, bias, r, res_up, True)
+            assert float(ref.abs().max()) <= 256
+            assert torch.equal(out.float(), ref)
+
+
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
 def test_conv_unit_random_data_full_tile_shapes(engine, cin, cout, in_up):
     import torch
