@@ -83,6 +83,13 @@ struct ConvArgs {
   const uint4* pin;    // fused 1x1 projection: raw input [N, H, W, pcs*8] bf16 (NULL: none)
   const uint4* pwpk;   // its packed weights ([cout block][k-step][lane]); the projection's bias rides in `bias`
   int pcs;             // 16-byte units per projection input pixel
+  // fused output head (the network's last unit): y[n, o, p] = hbias[o] + sum_c hw[o, c] * bf16(relu(hscale[c] * OUT[n, p, c] + hshift[c]))
+  const float* hscale;
+  const float* hshift;
+  const float* hw;     // [hO, COUT]
+  const float* hbias;  // [hO]
+  float* hout;         // [N, hO, H, W] float32, or NULL: no head
+  int hO;
   unsigned long long* trace;  // diagnostics: per-phase shader-clock stamps of workgroup 0 (NULL in production)
 };
 
@@ -174,19 +181,20 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int irow, i
   }
 }
 
-template <int CIN, int COUT, bool TALL = false, bool PACK = false>
+template <int CIN, int COUT, bool TALL = false, bool PACK = false, bool HEAD = false>
 struct ConvCfg {
   static constexpr int KC = CIN / 16;    // MFMA k-steps per tap
   static constexpr int NPL = CIN / 8;    // 16-byte channel-octet planes in LDS
   static constexpr int NCB = COUT / 32;  // blocks of 32 output channels
   // register budget per wave (256 VGPRs at 2 waves/SIMD): 9*KC*4 for the weights + 16*R accumulators
   // + the next tile's staging loads + the residual prefetch
-  static constexpr int R = CIN >= 64 ? 2 : 4;                      // output rows per wave and pass
+  // (HEAD: two rows per pass — the head's constants and sums need the registers of two rows of accumulators)
+  static constexpr int R = (CIN >= 64 || HEAD) ? 2 : 4;            // output rows per wave and pass
   // row passes per tile (accumulators reused); TALL doubles them: a taller tile has less halo per output row, taken
   // when the image height is a multiple of the taller tile
   // (packed launches: 14-row tiles — 28, 56 and 112 are multiples of 14 — so a 28-row level is 504 tiles for the chip's 512
   // workgroup slots and the halo is 2 rows in 16)
-  static constexpr int PASSES = (PACK && COUT >= 128) ? 7 : ((CIN >= 64 && COUT >= 64) ? 2 : 1) * (TALL ? 2 : 1);
+  static constexpr int PASSES = (PACK && COUT >= 128) ? 7 : ((CIN >= 64 && COUT >= 64) ? 2 : 1) * (TALL ? 2 : 1) * (HEAD ? 2 : 1);
   static constexpr int RG = 4 / NCB;                               // row groups per workgroup (4 waves)
   // PACK: one more window column, the zero column that separates two images meeting inside the 32-pixel block
   static constexpr int TH = RG * R * PASSES, TW = 32, LH = TH + 2, LW = TW + 2 + (PACK ? 1 : 0);
@@ -212,10 +220,16 @@ struct ConvCfg {
 // the next: the staging puts one zero column between them in LDS (the right halo of the first and the left halo of the
 // second), lanes past the seam read one slot further, and every lane keeps its own (image, column) for the residual,
 // the store and the pooled output.
-template <int CIN, int COUT, bool UP, bool POOL, int PK, bool TALL, bool PACK = false>
+//
+// HEAD: the network's output head rides in the last unit's epilogue — BatchNorm + ReLU + 1x1 convolution to <= 3 channels +
+// NHWC -> NCHW float32, from the accumulators: a lane holds 16 of a pixel's 32 channels, its partner (lane ^ 32) the other
+// 16.  Products are summed octet by octet, then octet pairs, then the two halves: the order of k_out_head, so both paths give
+// the same bits.  OUT may be NULL then (nothing else reads the last unit's output: 0.9 GB per forward not written, not re-read).
+template <int CIN, int COUT, bool UP, bool POOL, int PK, bool TALL, bool PACK = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   static_assert(!PACK || (!UP && PK == 0), "packed launches: plain input, no fused projection");
-  using cfg = ConvCfg<CIN, COUT, TALL, PACK>;
+  static_assert(!HEAD || (COUT == 32 && !POOL && PK == 0 && !PACK), "the fused head is built for the 32-channel last unit");
+  using cfg = ConvCfg<CIN, COUT, TALL, PACK, HEAD>;
   constexpr int PPLANE = (cfg::TH * cfg::TW) | 1;  // slot pitch of a projection-input octet plane
   constexpr int KC = cfg::KC, NPL = cfg::NPL, NCB = cfg::NCB, R = cfg::R, TH = cfg::TH, TW = cfg::TW;
   constexpr int LW = cfg::LW, RAW = cfg::RAW, PLANE = cfg::PLANE, PASSES = cfg::PASSES;
@@ -240,6 +254,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     for (int i = 0; i < PK; ++i) pfrag[i] = pp[i * 64];
   }
   uint4* const ldsP = lds + NPL * PLANE;
+  __shared__ float hconst[HEAD ? 5 * 32 + 4 : 1];  // head: scale, shift, three weight rows, bias
+  if constexpr (HEAD) {
+    if (tid < 32) {
+      hconst[tid] = a.hscale[tid];
+      hconst[32 + tid] = a.hshift[tid];
+#pragma unroll
+      for (int o = 0; o < 3; ++o) hconst[64 + 32 * o + tid] = o < a.hO ? a.hw[o * 32 + tid] : 0.f;
+      if (tid < 4) hconst[160 + tid] = tid < a.hO ? a.hbias[tid] : 0.f;
+    }
+    // (visible to every wave after the first tile's barriers)
+  }
   // ---- staging role of this thread: a fixed channel octet
   const int pl = tid % NPL, pix0 = tid / NPL;
   const int ly0 = pix0 / LW, lx0 = pix0 - ly0 * LW;  // window coordinates of this thread's first pixel
@@ -390,7 +415,42 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
             acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfrag[k], LP[2 * k * PPLANE + r * TW], acc[r], 0, 0, 0);
       }
       if (pass == PASSES - 1) CONV_STAMP(5);
-      conv_store<R>(a, nimg, irow, y0 + rbase, gx, c0, acc);
+      if constexpr (HEAD) {
+        float tot[R][3];
+        __builtin_amdgcn_sched_barrier(0);  // the constants are loaded here, not above the MFMA loop (they would spill the weights)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float hs[8], hb[8], w0[8], w1[8], w2[8];
+          const float* hc = hconst + c0 + 8 * half;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { hs[k] = hc[k]; hb[k] = hc[32 + k]; w0[k] = hc[64 + k]; w1[k] = hc[96 + k]; w2[k] = hc[128 + k]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float xb = cv_bf2f(cv_f2bf(acc[r][8 * half + k]));  // the value OUT holds
+              const float av = cv_bf2f(cv_f2bf(fmaxf(xb * hs[k] + hb[k], 0.0f)));
+              s0 += av * w0[k]; s1 += av * w1[k]; s2 += av * w2[k];
+            }
+            if (half == 0) { tot[r][0] = s0; tot[r][1] = s1; tot[r][2] = s2; }
+            else { tot[r][0] += s0; tot[r][1] += s1; tot[r][2] += s2; }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int o = 0; o < 3; ++o) tot[r][o] += __shfl_xor(tot[r][o], 32);
+          const int gy = y0 + rbase + r;
+          if (hh == 0 && gx < a.W && gy < a.H) {
+            float* hp = a.hout + (size_t)n * a.hO * a.H * a.W + (size_t)gy * a.W + gx;
+            for (int o = 0; o < a.hO; ++o) hp[(size_t)o * a.H * a.W] = tot[r][o] + hconst[160 + o];
+          }
+        }
+      }
+      if (!HEAD || a.out) conv_store<R>(a, nimg, irow, y0 + rbase, gx, c0, acc);
       // ---- the next level's input, max_pool2d(OUT, 2, 2), straight from the accumulators: row pairs are in this
       // wave's registers, column pairs are neighbouring lanes (max commutes with the bf16 rounding)
       if constexpr (POOL) {
@@ -693,6 +753,20 @@ int launch_conv_reg(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
       aliby_set_error("conv3x3: fused projection is built for (32,32) and (64,64) without upsampling only");
       return ALIBY_ERR_UNSUPPORTED;
     }
+  } else if (a.hout) {
+    if constexpr (COUT == 32 && CIN == 32 && !UP && !PACK) {
+      static bool head_attr = false;
+      if (!head_attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CIN, COUT, UP, false, 0, TALL, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, cfg::LDS_BYTES));
+        head_attr = true;
+      }
+      ARG_CHECK(!a.pool && a.hO >= 1 && a.hO <= 3, "conv3x3: fused head: 1..3 output channels, no pooled output");
+      hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, false, 0, TALL, false, true>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
+    } else {
+      aliby_set_error("conv3x3: the fused output head is built for the (32,32) unit only");
+      return ALIBY_ERR_UNSUPPORTED;
+    }
   } else if (a.pool) {
     hipLaunchKernelGGL((k_conv3x3<CIN, COUT, UP, true, 0, TALL, PACK>), dim3(8 * nslots), dim3(256), cfg::LDS_BYTES, stream, a);
   } else {
@@ -707,7 +781,7 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   // measured per shape (scripts/bench_conv.py): the DMA pipeline wins where the raw window is small (upsampled
   // input); ALIBY_CONV_DMA=0/1 forces one variant for A/B runs
   static const bool use_dma = [] { const char* e = getenv("ALIBY_CONV_DMA"); return e ? atoi(e) != 0 : UP; }();
-  if (use_dma && !a.pool && !a.pin) {  // the pooled output is an epilogue of the register-staged variant
+  if (use_dma && !a.pool && !a.pin && !a.hout) {  // the pooled output is an epilogue of the register-staged variant
     if constexpr (UP && COUT >= 64) {
       static const int pack_up = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) : 7; }();  // bit 2: upsampled shapes
       if ((pack_up & 4) && (a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0 && a.H % DmaCfg<CIN, COUT, UP, true>::TH == 0)
@@ -731,13 +805,16 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+struct HeadArgs { const float *scale, *shift, *w, *bias; float* out; int channels; };
+
 static int conv3x3_entry(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                          const float* shift, int shift_per_sample, const float* bias, const void* res,
                          int res_up, int N, int H, int W, int CIN, int COUT, int in_up,
                          int in_channels, int in_channel0, int out_channels, int out_channel0,
-                         void* pool_out, const void* proj_in, const void* proj_wpk, int proj_channels, void* stream_) {
+                         void* pool_out, const void* proj_in, const void* proj_wpk, int proj_channels, void* stream_,
+                         const HeadArgs* head = nullptr) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3: null argument");
+  ARG_CHECK(ctx && in && wpk && (out || head) && scale && shift, "conv3x3: null argument");
   ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3: empty shape");
   ARG_CHECK(!in_up || ((H & 1) == 0 && (W & 1) == 0), "conv3x3: upsampled input needs even H, W");
   ARG_CHECK(!res || !res_up || ((H & 1) == 0 && (W & 1) == 0), "conv3x3: upsampled residual needs even H, W");
@@ -762,6 +839,12 @@ static int conv3x3_entry(aliby_ctx* ctx, const void* in, const void* wpk, void* 
   a.ocs = out_channels / 8;
   a.ocoff = out_channel0 / 8;
   a.trace = g_conv_trace;
+  a.hscale = head ? head->scale : nullptr;
+  a.hshift = head ? head->shift : nullptr;
+  a.hw = head ? head->w : nullptr;
+  a.hbias = head ? head->bias : nullptr;
+  a.hout = head ? head->out : nullptr;
+  a.hO = head ? head->channels : 0;
   a.pin = static_cast<const uint4*>(proj_in);
   a.pwpk = static_cast<const uint4*>(proj_wpk);
   a.pcs = proj_channels / 8;
@@ -795,6 +878,18 @@ extern "C" int aliby_nn_conv3x3_proj_bf16(aliby_ctx* ctx, const void* in, const 
   ARG_CHECK(proj_in && proj_wpk, "conv3x3_proj: NULL projection operand");
   return conv3x3_entry(ctx, in, wpk, out, scale, shift, shift_per_sample, bias, nullptr, 0, N, H, W, CIN, COUT, 0, 0, 0, 0, 0, nullptr,
                        proj_in, proj_wpk, proj_channels, stream);
+}
+
+extern "C" int aliby_nn_conv3x3_head_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out_or_null, const float* scale,
+                                          const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
+                                          int N, int H, int W, int CIN, int COUT, const float* head_scale, const float* head_shift,
+                                          const float* head_w, const float* head_bias, int head_channels, float* head_out,
+                                          void* stream) {
+  ARG_CHECK(head_scale && head_shift && head_w && head_bias && head_out, "conv3x3_head: NULL head operand");
+  ARG_CHECK(CIN == 32 && COUT == 32, "conv3x3_head: built for the 32 -> 32 unit");
+  const HeadArgs head = {head_scale, head_shift, head_w, head_bias, head_out, head_channels};
+  return conv3x3_entry(ctx, in, wpk, out_or_null, scale, shift, shift_per_sample, bias, res, res_up, N, H, W, CIN, COUT, 0, 0, 0, 0, 0,
+                       nullptr, nullptr, nullptr, 0, stream, &head);
 }
 
 extern "C" int aliby_debug_conv_trace(aliby_ctx* ctx, void* stamps_dev) {

@@ -18,6 +18,8 @@ Same arithmetic as `ResidualUNet.forward` in eval mode, reorganised for MI355X:
 
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -79,6 +81,7 @@ class FusedUNet:
         assert dtype == torch.bfloat16, "the fused kernels are bf16"
         self.eng, self.dtype = eng, dtype
         self.mfma_levels = tuple(mfma_levels)
+        self.fused_head = os.environ.get("ALIBY_NET_FUSED_HEAD", "1") != "0"
         self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
         self.lib, self.h = eng.lib, eng.ctx.handle
         net = net.float().eval()
@@ -186,6 +189,31 @@ class FusedUNet:
                 cur, cur_up = out, False
         return (out, pooled) if pool else out
 
+    def _unit_head(self, x, unit, shift, bias, res, y):
+        """The network's last unit with the output head in its epilogue (aliby_nn_conv3x3_head_bf16): y float32 [N,O,H,W]
+        is written from the accumulators and the unit's own bf16 output — which nothing else reads — is not written."""
+        n, cin, H, W = x.shape
+        cout = unit.w32.shape[0]
+        if unit.wpk is None:
+            unit.wpk = {}
+        key = (0, cin, 0, cout)
+        if key not in unit.wpk:
+            pk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(unit.w32), cout, cin, cin, _ptr(pk), _stream_ptr()))
+            unit.wpk[key] = pk
+        sh = unit.shift if shift is None else shift
+        group = "conv3x3_mfma"
+        timer = self.eng.timed(group)
+        if timer.active:
+            st = self.conv_stats.setdefault(group, [0, 0])
+            st[0] += 2 * (x.numel() + res.numel()) + 4 * y.numel()
+            st[1] += 2 * (9 * cin + y.shape[1]) * cout * n * H * W
+        with timer:
+            _lib.check(self.lib.aliby_nn_conv3x3_head_bf16(
+                self.h, _ptr(x), _ptr(unit.wpk[key]), 0, _ptr(unit.scale), _ptr(sh), self._sps(sh), _ptr(bias), _ptr(res), 0, n, H, W,
+                cin, cout, _ptr(self.out.scale), _ptr(self.out.shift), _ptr(self.out_w), _ptr(self.out.bias), self.out_w.shape[0], _ptr(y),
+                _stream_ptr()))
+
     def _unit_proj(self, x, unit, shift, bias, x_in, proj):
         """conv3x3(relu(scale*x + shift)) + bias + proj(x_in) in ONE launch (aliby_nn_conv3x3_proj_bf16): the residual
         block's 1x1 projection of its raw input is a few extra k-steps, its output never touches HBM."""
@@ -276,13 +304,16 @@ class FusedUNet:
         c2 = self._unit(x1, u[2], bias=u[2].bias)
         return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=i + 1 < len(self.down) and u[3].w32.shape[0] <= 128)  # (x2, maxpool(x2))
 
-    def _up_mfma(self, d, x, skip, style, up=True):
+    def _up_mfma(self, d, x, skip, style, up=True, head_out=None):
         u = d["u"]
         p_low = self._proj(x, d["proj"])  # 1x1 at the low resolution, read through the upsample as a residual
         c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=up)  # wider than one launch holds: split along K / N
         sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
         x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=up)
         c2 = self._unit(x1, u[2], shift=sh[1], bias=u[2].bias)
+        if head_out is not None:
+            self._unit_head(c2, u[3], sh[2], u[3].bias, x1, head_out)
+            return None
         return self._unit(c2, u[3], shift=sh[2], bias=u[3].bias, res=x1)
 
     # -------------------------------------------------------------------------------- forward
@@ -335,12 +366,19 @@ class FusedUNet:
             _lib.check(self.lib.aliby_nn_style_bf16(self.h, _ptr(deep), n, deep.shape[2], deep.shape[3], deep.shape[1], _ptr(self.style_w),
                                                     _ptr(self.style_b), self.style_b.numel(), _ptr(style), _ptr(self._style_all), _stream_ptr()))
         x, up = feats[-1], False
+        y = out if out is not None else torch.empty((n, self.out_w.shape[0], H, W), dtype=torch.float32, device="cuda")
+        assert y.is_contiguous() and y.dtype == torch.float32 and tuple(y.shape) == (n, self.out_w.shape[0], H, W)
         for i in range(len(self.up) - 1, -1, -1):
             d = self.up[i]
             u = d["u"]
             skip = feats[i]
             if i in self.mfma_levels:
-                x = self._up_mfma(d, x, skip, style, up)
+                # the last unit carries the output head in its epilogue (ALIBY_NET_FUSED_HEAD=0: separate k_out_head launch)
+                fuse_head = (i == 0 and self.fused_head and u[3].w32.shape[0] == 32 and u[3].w32.shape[1] == 32
+                             and self.out_w.shape[0] <= 3)
+                x = self._up_mfma(d, x, skip, style, up, head_out=y if fuse_head else None)
+                if fuse_head:
+                    return y, style
                 up = True
                 continue
             p_low = self._conv(x, d["proj"], pad=0)                 # at x's resolution; read through the upsample below
@@ -355,8 +393,6 @@ class FusedUNet:
             c3 = self._conv(a3, u[3])
             x, _ = self._fused(x1, c3, want_sum=True, bias=u[3].bias)
             up = True
-        y = out if out is not None else torch.empty((n, self.out_w.shape[0], H, W), dtype=torch.float32, device="cuda")
-        assert y.is_contiguous() and y.dtype == torch.float32 and tuple(y.shape) == (n, self.out_w.shape[0], H, W)
         if x.shape[1] == 32:
             with self.eng.timed("out_head"):
                 _lib.check(self.lib.aliby_nn_out_head_bf16(self.h, _ptr(x), _ptr(self.out.scale), _ptr(self.out.shift), _ptr(self.out_w),

@@ -194,6 +194,16 @@ int aliby_nn_conv3x3_proj_bf16(aliby_ctx* ctx, const void* in, const void* wpk, 
                                const float* shift, int shift_per_sample, const float* bias, int N, int H, int W,
                                int CIN, int COUT, const void* proj_in, const void* proj_wpk, int proj_channels,
                                void* stream);
+/* The network's LAST unit with the output head in its epilogue (cellpose CPnet.output: BatchNorm + ReLU + 1x1 convolution
+ * to `head_channels` <= 3 maps, segment/unet.py): head_out [N, head_channels, H, W] float32 =
+ * head_bias[o] + sum_c head_w[o, c] * bf16(relu(head_scale[c] * OUT[c] + head_shift[c])) — bit-identical to running
+ * aliby_nn_out_head_bf16 on the unit's bf16 output.  out_or_null = NULL skips writing that output (nothing else reads
+ * it).  Built for the 32 -> 32 unit. */
+int aliby_nn_conv3x3_head_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out_or_null, const float* scale,
+                               const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
+                               int N, int H, int W, int CIN, int COUT, const float* head_scale,
+                               const float* head_shift, const float* head_w, const float* head_bias, int head_channels,
+                               float* head_out, void* stream);
 /* float32 OIHW [COUT, CIN_src, 3, 3] device weights -> the MFMA fragment order the kernel above reads
  * ([COUT/32][9 taps][CIN/16][64 lanes][8] bf16, COUT*CIN*9*2 bytes; input channels >= CIN_src are zero). */
 int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk,

@@ -134,6 +134,45 @@ def test_conv_unit_packed_with_upsampled_input(engine, shape, cout, res_up):
             assert torch.equal(out.float(), ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 44, 70), (1, 10, 6), (2, 64, 32)])
+@pytest.mark.parametrize("O", [1, 3])
+def test_conv_unit_with_fused_output_head(engine, shape, O):
+    """The last unit with the output head in its epilogue == the unit followed by aliby_nn_out_head_bf16, bit for bit,
+    with and without writing the unit's own output."""
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    n, H, W = shape
+    g = torch.Generator().manual_seed(n * 10 + O)
+    x = torch.randn(n, H, W, 32, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).float().cuda()
+    scale = (torch.rand(32, generator=g) + 0.5).float().cuda()
+    shift = (torch.randn(n, 32, generator=g) * 0.2).float().cuda()
+    bias = (torch.randn(32, generator=g) * 0.1).float().cuda()
+    res = torch.randn(n, H, W, 32, generator=g).to(torch.bfloat16).cuda()
+    hs = (torch.rand(32, generator=g) + 0.5).float().cuda()
+    hb = (torch.randn(32, generator=g) * 0.2).float().cuda()
+    hw = (torch.randn(O, 32, generator=g) * 0.3).float().cuda()
+    hbias = torch.randn(O, generator=g).float().cuda()
+    out = _run(engine, x, w, scale, shift, bias, res, False, False, H, W)
+    want = torch.full((n, O, H, W), float("nan"), device="cuda")
+    _lib.check(engine.lib.aliby_nn_out_head_bf16(engine.ctx.handle, _ptr(out), _ptr(hs), _ptr(hb), _ptr(hw), _ptr(hbias), n, H, W, 32, O,
+                                                 _ptr(want), _stream_ptr()))
+    wpk = torch.empty(32 * 32 * 9, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), 32, 32, 32, _ptr(wpk), _stream_ptr()))
+    for keep in (False, True):
+        got = torch.full((n, O, H, W), float("nan"), device="cuda")
+        out2 = torch.full_like(out, float("nan")) if keep else None
+        _lib.check(engine.lib.aliby_nn_conv3x3_head_bf16(
+            engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out2) if keep else 0, _ptr(scale), _ptr(shift), 32, _ptr(bias), _ptr(res), 0, n, H, W,
+            32, 32, _ptr(hs), _ptr(hb), _ptr(hw), _ptr(hbias), O, _ptr(got), _stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        if keep:
+            assert torch.equal(out2, out)
+
+
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
 def test_conv_unit_random_data_full_tile_shapes(engine, cin, cout, in_up):
     import torch

@@ -207,6 +207,14 @@ def test_fused_unet_matches_module_forward(engine):
         assert err < 0.03, (levels, float(err))
         assert ((s - s_ref).norm() / s_ref.norm()) < 0.03
         print("fused unet", levels, "rel l2 err vs fp32 module:", float(err))
+    # the output head in the last unit's epilogue gives the bits of the separate head kernel
+    with_head = FusedUNet(net, engine)
+    separate = FusedUNet(net, engine)
+    separate.fused_head = False
+    assert with_head.fused_head
+    ya, _ = with_head(x)
+    yb, _ = separate(x)
+    assert torch.equal(ya, yb)
 
 
 def test_dynamics_large_mask_uses_global_scratch(engine):
