@@ -89,6 +89,8 @@ _SIGNATURES = {
     "aliby_nn_pack_conv1x1_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "aliby_nn_conv3x3_proj_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "aliby_nn_conv3x3_head_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "aliby_nn_conv3x3_pair_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                        _i, _vp, _vp]),
     "aliby_nn_conv1x1_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "aliby_nn_first_conv_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aliby_nn_style_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -90,6 +90,12 @@ struct ConvArgs {
   const float* hbias;  // [hO]
   float* hout;         // [N, hO, H, W] float32, or NULL: no head
   int hO;
+  // second unit of a fused pair (k_conv_pair32): OUT = conv_B(act_B(conv_A(act_A(IN)) + bias_A)) + bias_B + RES
+  const uint4* wpk2;
+  const float* scale2;
+  const float* shift2;
+  const float* bias2;
+  int shift2_stride;
   unsigned long long* trace;  // diagnostics: per-phase shader-clock stamps of workgroup 0 (NULL in production)
 };
 
@@ -676,6 +682,255 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP, PACK>::WAVES_PER_SIMD))
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two units of a 32-channel residual block in one launch (cellpose resdown / resup: x + conv3(conv2(x))): the tensor
+// between them — 0.9 GB written and read back per 288-tile forward at 224 x 224 — stays in LDS.
+//
+// Wave-specialised: an 8-wave workgroup, one per CU.  Waves 0-3 (producers) hold unit A's weights: they stage the 18 x 34
+// input window of a tile through A's prologue, compute the 16 x 32 intermediate block (one MFMA block wide: tiles are 30
+// output pixels wide so that the one-pixel halo fills the block), round it to bf16 exactly where the two-launch path
+// stores it, run it through unit B's prologue (BatchNorm affine + style shift + ReLU, zero outside the image) and write it
+// into one of two sets of channel-octet planes.  Waves 4-7 (consumers) hold unit B's weights and turn the previous tile's
+// planes into 14 x 30 output pixels (+ residual, + pooled output) meanwhile.  One weight set per wave: no spills, and the
+// consumers' MFMAs overlap the producers' load latency.  Every wave passes the same two barriers per tile:
+//     producers:  stage window(t)        | S1 | unit A -> planes[t & 1]   | S2 |
+//     consumers:  unit B pass 0 of t - 1 | S1 | unit B pass 1 of t - 1    | S2 |
+// Same bits as the two launches.
+// ------------------------------------------------------------------------------------------------
+struct PairCfg {
+  static constexpr int KC = 2, NPL = 4, R = 2, PASSES = 2;
+  static constexpr int TH = 14, TWO = 30, MH = 16, MW = 32, IH = 18, IW = 34;
+  static constexpr int RAW_IN = IH * IW, PLANE_IN = RAW_IN + (10 - RAW_IN % 8) % 8;
+  static constexpr int RAW_MID = MH * MW, PLANE_MID = RAW_MID + (10 - RAW_MID % 8) % 8;
+  static constexpr int PIX_PER_IT = 256 / NPL, ITERS = (RAW_IN + PIX_PER_IT - 1) / PIX_PER_IT;
+  static constexpr int MID_SLOTS = NPL * PLANE_MID + 8;
+  static constexpr int SLOTS = NPL * PLANE_IN + 2 * MID_SLOTS;
+  static constexpr int LDS_BYTES = SLOTS * 16;
+  static constexpr int DEPTH = 6;
+};
+
+template <bool POOL, bool HEAD>
+__global__ __launch_bounds__(512, 1) void k_conv_pair32(ConvArgs a) {
+  static_assert(!(POOL && HEAD), "either the pooled output (down block) or the output head (last unit)");
+  using cfg = PairCfg;
+  constexpr int KC = cfg::KC, NPL = cfg::NPL, R = cfg::R, PASSES = cfg::PASSES, TH = cfg::TH, TWO = cfg::TWO;
+  constexpr int IW_ = cfg::IW, MW = cfg::MW, PLANE_IN = cfg::PLANE_IN, PLANE_MID = cfg::PLANE_MID, RAW_IN = cfg::RAW_IN;
+  constexpr int PIX_PER_IT = cfg::PIX_PER_IT, ITERS = cfg::ITERS;
+  extern __shared__ uint4 lds[];
+  uint4* const ldsIn = lds;
+  uint4* const ldsMid0 = lds + NPL * PLANE_IN;
+  __shared__ __align__(16) float tabB[64];  // unit B's scale[32], shift[32] of the producers' current tile
+  __shared__ float hconst[HEAD ? 5 * 32 + 4 : 1];  // output head: scale, shift, three weight rows, bias (see k_conv3x3)
+
+  const int consumer = threadIdx.x >> 8;            // wave-uniform: waves 4-7
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // role-local thread / wave index
+  const int px = lane & 31, hh = lane >> 5;
+  const int c0 = hh * 16;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd + slot, t_end = min(a.ntiles, (xcd + 1) * per_xcd);
+  const int my_tiles = t_begin < t_end ? (t_end - t_begin + nslots - 1) / nslots : 0;  // the same for both roles
+
+  if (!consumer) {
+    // =============================================================== producers: window -> unit A -> B's planes
+    bf16x8_t wA[9 * KC];
+    {
+      const bf16x8_t* pa = reinterpret_cast<const bf16x8_t*>(a.wpk) + lane;
+#pragma unroll
+      for (int i = 0; i < 9 * KC; ++i) wA[i] = pa[i * 64];
+    }
+    const int pl = tid % NPL, pix0 = tid / NPL;
+    const int ly0 = pix0 / IW_, lx0 = pix0 - ly0 * IW_;
+    f32x2_t sc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sc[k] = f32x2_t{a.scale[pl * 8 + 2 * k], a.scale[pl * 8 + 2 * k + 1]};
+    // the window of tile t + 1 is requested while unit A works on tile t: its loads are in flight behind the MFMA loop
+    uint4 v[ITERS];
+    unsigned inside = 0;
+    auto request = [&](int tile) {
+      const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+      const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TWO;
+      const uint4* inN = a.in + (size_t)n * a.H * a.W * a.cs + a.coff;
+      inside = 0;
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) {
+        int lx = lx0 + (u * PIX_PER_IT) % IW_, ly = ly0 + (u * PIX_PER_IT) / IW_;
+        if (lx >= IW_) { lx -= IW_; ly += 1; }
+        const int gy = y0 - 2 + ly, gxi = x0 - 2 + lx;
+        inside |= (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W) << u;
+        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gxi, 0), a.W - 1);
+        v[u] = inN[(unsigned)((cy * a.W + cx) * a.cs + pl)];
+      }
+    };
+    if (my_tiles > 0) request(t_begin);
+    for (int it = 0; it < my_tiles; ++it) {
+      const int tile = t_begin + it * nslots;
+      const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+      const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TWO;
+      uint4* const ldsMid = ldsMid0 + (it & 1) * cfg::MID_SLOTS;
+      f32x2_t sh[4];
+      {
+        const float* sp = a.shift + (size_t)n * a.shift_stride + pl * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[k] = f32x2_t{sp[2 * k], sp[2 * k + 1]};
+      }
+      if (tid < 32) {  // (read by the producers only, after S1)
+        tabB[tid] = a.scale2[tid];
+        tabB[32 + tid] = a.shift2[(size_t)n * a.shift2_stride + tid];
+      }
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) {
+        const uint4 o = conv_act8(v[u], sc, sh, 0u - ((inside >> u) & 1u));
+        if (u == ITERS - 1 && pix0 + u * PIX_PER_IT >= RAW_IN) continue;
+        ldsIn[pl * PLANE_IN + pix0 + u * PIX_PER_IT] = o;
+      }
+      __syncthreads();  // S1: the window is complete
+      if (it + 1 < my_tiles) request(tile + nslots);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int mbase = (wave * PASSES + pass) * R;  // first intermediate row of this wave and pass (image row y0 - 1 + mbase)
+        f32x16_t acc[R];
+        {
+          float4 b4[4] = {};
+          if (a.bias) {
+            const float4* bp = reinterpret_cast<const float4*>(a.bias + c0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+          }
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        conv_mfma<R, KC, cfg::DEPTH, PLANE_IN, IW_>(reinterpret_cast<const bf16x8_t*>(ldsIn) + hh * PLANE_IN + mbase * IW_ + px, wA, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        // bf16 as the two-launch path stores it, then B's prologue; zero where the intermediate pixel lies outside the image
+        const int mgx = x0 - 1 + px;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int mgy = y0 - 1 + mbase + r;
+          const unsigned keep = 0u - (unsigned)((unsigned)mgy < (unsigned)a.H && (unsigned)mgx < (unsigned)a.W);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            f32x2_t s2[4], h2[4];
+            const float4* tp = reinterpret_cast<const float4*>(tabB + c0 + 8 * half);
+            const float4 sa = tp[0], sb = tp[1], ha = tp[8], hb = tp[9];
+            s2[0] = f32x2_t{sa.x, sa.y}; s2[1] = f32x2_t{sa.z, sa.w}; s2[2] = f32x2_t{sb.x, sb.y}; s2[3] = f32x2_t{sb.z, sb.w};
+            h2[0] = f32x2_t{ha.x, ha.y}; h2[1] = f32x2_t{ha.z, ha.w}; h2[2] = f32x2_t{hb.x, hb.y}; h2[3] = f32x2_t{hb.z, hb.w};
+            const uint4 raw = make_uint4(cv_pack2(acc[r][8 * half + 0], acc[r][8 * half + 1]), cv_pack2(acc[r][8 * half + 2], acc[r][8 * half + 3]),
+                                         cv_pack2(acc[r][8 * half + 4], acc[r][8 * half + 5]), cv_pack2(acc[r][8 * half + 6], acc[r][8 * half + 7]));
+            ldsMid[(2 * hh + half) * PLANE_MID + (mbase + r) * MW + px] = conv_act8(raw, s2, h2, keep);
+          }
+        }
+      }
+      __syncthreads();  // S2: planes[it & 1] are complete; the window (and tabB) may be overwritten
+    }
+    __syncthreads();  // the consumers' last tile: its S1 ...
+    __syncthreads();  // ... and S2
+  } else {
+    // =============================================================== consumers: B's planes -> unit B -> OUT
+    bf16x8_t wB[9 * KC];
+    {
+      const bf16x8_t* pb = reinterpret_cast<const bf16x8_t*>(a.wpk2) + lane;
+#pragma unroll
+      for (int i = 0; i < 9 * KC; ++i) wB[i] = pb[i * 64];
+    }
+    if constexpr (HEAD) {
+      if (tid < 32) {
+        hconst[tid] = a.hscale[tid];
+        hconst[32 + tid] = a.hshift[tid];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) hconst[64 + 32 * o + tid] = o < a.hO ? a.hw[o * 32 + tid] : 0.f;
+        if (tid < 4) hconst[160 + tid] = tid < a.hO ? a.hbias[tid] : 0.f;
+      }  // (visible to the consumers after the two fill barriers below)
+    }
+    float4 b4[4] = {};
+    if (a.bias2) {
+      const float4* bp = reinterpret_cast<const float4*>(a.bias2 + c0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+    }
+    __syncthreads();  // the producers' first tile: its S1 ...
+    __syncthreads();  // ... and S2
+    for (int it = 0; it < my_tiles; ++it) {
+      const int tile = t_begin + it * nslots;
+      const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+      const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TWO;
+      const uint4* const ldsMid = ldsMid0 + (it & 1) * cfg::MID_SLOTS;
+      const int gx = (px < TWO && x0 + px < a.W) ? x0 + px : a.W;  // a.W: this lane stores nothing
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int rbase = (wave * PASSES + pass) * R;
+        if (rbase < TH) {  // (the last wave's second pass has no rows)
+          uint4 rr[R][2];
+          if (a.res) conv_load_res<R>(a, n, 0, y0 + rbase, min(gx, a.W - 1), c0, rr);
+          f32x16_t acc[R];
+          conv_seed<R>(acc, b4, rr, a.res != nullptr);
+          __builtin_amdgcn_sched_barrier(0);
+          conv_mfma<R, KC, cfg::DEPTH, PLANE_MID, MW>(reinterpret_cast<const bf16x8_t*>(ldsMid) + hh * PLANE_MID + rbase * MW + px, wB, acc);
+          if constexpr (HEAD) {  // the output head from the accumulators, in k_out_head's summation order (see k_conv3x3)
+            float tot[R][3];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              float hs[8], hb[8], w0[8], w1[8], w2[8];
+              const float* hc = hconst + c0 + 8 * half;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) { hs[k] = hc[k]; hb[k] = hc[32 + k]; w0[k] = hc[64 + k]; w1[k] = hc[96 + k]; w2[k] = hc[128 + k]; }
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  const float xb = cv_bf2f(cv_f2bf(acc[r][8 * half + k]));
+                  const float av = cv_bf2f(cv_f2bf(fmaxf(xb * hs[k] + hb[k], 0.0f)));
+                  s0 += av * w0[k]; s1 += av * w1[k]; s2 += av * w2[k];
+                }
+                if (half == 0) { tot[r][0] = s0; tot[r][1] = s1; tot[r][2] = s2; }
+                else { tot[r][0] += s0; tot[r][1] += s1; tot[r][2] += s2; }
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+              for (int o = 0; o < 3; ++o) tot[r][o] += __shfl_xor(tot[r][o], 32);
+              const int gy = y0 + rbase + r;
+              if (hh == 0 && gx < a.W && gy < a.H) {
+                float* hp = a.hout + (size_t)n * a.hO * a.H * a.W + (size_t)gy * a.W + gx;
+                for (int o = 0; o < a.hO; ++o) hp[(size_t)o * a.H * a.W] = tot[r][o] + hconst[160 + o];
+              }
+            }
+          }
+          if (!HEAD || a.out) conv_store<R>(a, n, 0, y0 + rbase, gx, c0, acc);
+          if constexpr (POOL) {
+            const int PH = a.H >> 1, PW = a.W >> 1;
+            const int gy = y0 + rbase;
+            const bool writer = (px & 1) == 0 && gx + 1 < a.W && gy + 1 < a.H;
+            uint4* pp = a.pool + (size_t)n * PH * PW * a.ocs + a.ocoff + (unsigned)(((gy >> 1) * PW + (min(gx, a.W - 1) >> 1)) * a.ocs + (c0 >> 3));
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              unsigned pk[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float v0 = fmaxf(acc[0][half * 8 + 2 * q], acc[1][half * 8 + 2 * q]);
+                const float v1 = fmaxf(acc[0][half * 8 + 2 * q + 1], acc[1][half * 8 + 2 * q + 1]);
+                pk[q] = cv_pack2(fmaxf(v0, __shfl_xor(v0, 1)), fmaxf(v1, __shfl_xor(v1, 1)));
+              }
+              if (writer) pp[half] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+          }
+        }
+        __syncthreads();  // pass 0: the producers' S1 of tile it + 1 (or their drain); pass 1: S2
+      }
+    }
+  }
+}
+
 // Packed layout: [cout block cb][tap][k-step kc][lane][8 bf16]; lane l holds the MFMA A fragment
 // A[row m = l&31][k = 8*(l>>5) + j] = W[cb*32 + chan(m)][cin = 16*kc + 8*(l>>5) + j][tap], with
 // chan(m) = 16*((m>>2)&1) + (m&3) + 4*(m>>3) (see the header comment).
@@ -890,6 +1145,56 @@ extern "C" int aliby_nn_conv3x3_head_bf16(aliby_ctx* ctx, const void* in, const 
   const HeadArgs head = {head_scale, head_shift, head_w, head_bias, head_out, head_channels};
   return conv3x3_entry(ctx, in, wpk, out_or_null, scale, shift, shift_per_sample, bias, res, res_up, N, H, W, CIN, COUT, 0, 0, 0, 0, 0,
                        nullptr, nullptr, nullptr, 0, stream, &head);
+}
+
+extern "C" int aliby_nn_conv3x3_pair_bf16(aliby_ctx* ctx, const void* in, const void* wpk_a, const void* wpk_b, void* out_or_null,
+                                          const float* scale_a, const float* shift_a, int shift_a_per_sample, const float* bias_a,
+                                          const float* scale_b, const float* shift_b, int shift_b_per_sample, const float* bias_b,
+                                          const void* res, int N, int H, int W, void* pool_out, const float* head_scale,
+                                          const float* head_shift, const float* head_w, const float* head_bias, int head_channels,
+                                          float* head_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ARG_CHECK(ctx && in && wpk_a && wpk_b && (out_or_null || head_out) && scale_a && shift_a && scale_b && shift_b, "conv3x3_pair: null argument");
+  ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3_pair: empty shape");
+  ARG_CHECK(!pool_out || ((H & 1) == 0 && (W & 1) == 0), "conv3x3_pair: pooled output needs even H, W");
+  ARG_CHECK(!head_out || (head_scale && head_shift && head_w && head_bias && head_channels >= 1 && head_channels <= 3 && !pool_out),
+            "conv3x3_pair: the fused head needs its operands, 1..3 channels and no pooled output");
+  ARG_CHECK(!pool_out || out_or_null, "conv3x3_pair: the pooled output comes with the full output");
+  ConvArgs a = {};
+  a.in = static_cast<const uint4*>(in);
+  a.wpk = static_cast<const uint4*>(wpk_a);
+  a.wpk2 = static_cast<const uint4*>(wpk_b);
+  a.out = static_cast<uint4*>(out_or_null);
+  a.pool = static_cast<uint4*>(pool_out);
+  a.scale = scale_a; a.shift = shift_a; a.bias = bias_a;
+  a.scale2 = scale_b; a.shift2 = shift_b; a.bias2 = bias_b;
+  a.shift_stride = shift_a_per_sample == 1 ? 32 : shift_a_per_sample;
+  a.shift2_stride = shift_b_per_sample == 1 ? 32 : shift_b_per_sample;
+  a.res = static_cast<const uint4*>(res);
+  a.res_up = 0;
+  a.cs = 4; a.coff = 0; a.ocs = 4; a.ocoff = 0;
+  a.N = N; a.H = H; a.W = W; a.G = 1;
+  a.hscale = head_scale; a.hshift = head_shift; a.hw = head_w; a.hbias = head_bias; a.hout = head_out; a.hO = head_out ? head_channels : 0;
+  a.tiles_x = (W + PairCfg::TWO - 1) / PairCfg::TWO;
+  a.tiles_y = (H + PairCfg::TH - 1) / PairCfg::TH;
+  const long long nt = (long long)N * a.tiles_x * a.tiles_y;
+  ARG_CHECK(nt < INT_MAX, "conv3x3_pair: too many tiles");
+  a.ntiles = (int)nt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_pair32<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_pair32<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_pair32<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg::LDS_BYTES));
+    attr_done = true;
+  }
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int nslots = per_xcd < 32 ? per_xcd : 32;  // one 8-wave workgroup per CU, 32 CUs per XCD
+  const dim3 grid(8 * nslots), block(512);
+  if (head_out) hipLaunchKernelGGL((k_conv_pair32<false, true>), grid, block, PairCfg::LDS_BYTES, stream, a);
+  else if (pool_out) hipLaunchKernelGGL((k_conv_pair32<true, false>), grid, block, PairCfg::LDS_BYTES, stream, a);
+  else hipLaunchKernelGGL((k_conv_pair32<false, false>), grid, block, PairCfg::LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
 }
 
 extern "C" int aliby_debug_conv_trace(aliby_ctx* ctx, void* stamps_dev) {

@@ -82,6 +82,7 @@ class FusedUNet:
         self.eng, self.dtype = eng, dtype
         self.mfma_levels = tuple(mfma_levels)
         self.fused_head = os.environ.get("ALIBY_NET_FUSED_HEAD", "1") != "0"
+        self.fused_pair = os.environ.get("ALIBY_NET_FUSED_PAIR", "1") != "0"  # level 0: conv2 + conv3 of a block in one launch
         self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
         self.lib, self.h = eng.lib, eng.ctx.handle
         net = net.float().eval()
@@ -187,6 +188,43 @@ class FusedUNet:
                 self._launch_unit(x, unit, (k0, k0 + ks), (n0, n0 + ns), out, shift, bias if last else None, cur, cur_up, in_up,
                                   pooled if last else None)
                 cur, cur_up = out, False
+        return (out, pooled) if pool else out
+
+    def _pack(self, unit):
+        cout, cin = unit.w32.shape[0], unit.w32.shape[1]
+        if unit.wpk is None:
+            unit.wpk = {}
+        key = (0, cin, 0, cout)
+        if key not in unit.wpk:
+            pk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv3x3_bf16(self.h, _ptr(unit.w32), cout, cin, cin, _ptr(pk), _stream_ptr()))
+            unit.wpk[key] = pk
+        return unit.wpk[key]
+
+    def _pair(self, x, ua, ub, shift_a, shift_b, bias_a, bias_b, res, pool=False, head_out=None):
+        """Two consecutive 32-channel units in one launch (aliby_nn_conv3x3_pair_bf16): the tensor between them stays in
+        LDS.  With `head_out` the network's output head is taken from the second unit's accumulators and its own output is
+        not written; with `pool` the next level's input is written beside the output."""
+        n, cin, H, W = x.shape
+        sa = ua.shift if shift_a is None else shift_a
+        sb = ub.shift if shift_b is None else shift_b
+        out = None if head_out is not None else self._new(n, 32, H, W)
+        pooled = self._new(n, 32, H // 2, W // 2) if pool else None
+        group = "conv3x3_mfma_pair"
+        timer = self.eng.timed(group)
+        if timer.active:
+            st = self.conv_stats.setdefault(group, [0, 0])
+            st[0] += 2 * (x.numel() + res.numel()) + (2 * x.numel() if out is not None else 4 * head_out.numel()) + (x.numel() // 2 if pool else 0)
+            st[1] += 2 * 2 * 9 * 32 * 32 * n * H * W
+        hd = self.out
+        with timer:
+            _lib.check(self.lib.aliby_nn_conv3x3_pair_bf16(
+                self.h, _ptr(x), _ptr(self._pack(ua)), _ptr(self._pack(ub)), _ptr(out) if out is not None else 0, _ptr(ua.scale), _ptr(sa),
+                self._sps(sa), _ptr(bias_a), _ptr(ub.scale), _ptr(sb), self._sps(sb), _ptr(bias_b), _ptr(res), n, H, W,
+                _ptr(pooled) if pooled is not None else 0,
+                _ptr(hd.scale) if head_out is not None else 0, _ptr(hd.shift) if head_out is not None else 0,
+                _ptr(self.out_w) if head_out is not None else 0, _ptr(hd.bias) if head_out is not None else 0,
+                self.out_w.shape[0] if head_out is not None else 0, _ptr(head_out) if head_out is not None else 0, _stream_ptr()))
         return (out, pooled) if pool else out
 
     def _unit_head(self, x, unit, shift, bias, res, y):
@@ -301,8 +339,11 @@ class FusedUNet:
             x1 = self._unit_proj(c0, u[1], sh1, d["pb1"], x_raw, d["proj"])
         else:
             x1 = self._unit(c0, u[1], shift=sh1, bias=d["pb1"], res=p)
+        pool = i + 1 < len(self.down) and u[3].w32.shape[0] <= 128
+        if self.fused_pair and tuple(u[2].w32.shape[:2]) == (32, 32) and tuple(u[3].w32.shape[:2]) == (32, 32):
+            return self._pair(x1, u[2], u[3], None, None, u[2].bias, u[3].bias, x1, pool=pool)
         c2 = self._unit(x1, u[2], bias=u[2].bias)
-        return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=i + 1 < len(self.down) and u[3].w32.shape[0] <= 128)  # (x2, maxpool(x2))
+        return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=pool)  # (x2, maxpool(x2))
 
     def _up_mfma(self, d, x, skip, style, up=True, head_out=None):
         u = d["u"]
@@ -310,6 +351,10 @@ class FusedUNet:
         c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=up)  # wider than one launch holds: split along K / N
         sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
         x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=up)
+        # (with the output head in its consumers' epilogue the pair measures 1139 us against 454 + 610 for conv2 and the
+        # unit-with-head launch: the head's arithmetic lands on the four consumer waves only — so the last block keeps two launches)
+        if self.fused_pair and head_out is None and tuple(u[2].w32.shape[:2]) == (32, 32) and tuple(u[3].w32.shape[:2]) == (32, 32):
+            return self._pair(x1, u[2], u[3], sh[1], sh[2], u[2].bias, u[3].bias, x1)
         c2 = self._unit(x1, u[2], shift=sh[1], bias=u[2].bias)
         if head_out is not None:
             self._unit_head(c2, u[3], sh[2], u[3].bias, x1, head_out)

@@ -294,7 +294,7 @@ def main():
                          "timed_launches": g["timed_launches"],
                          "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
     net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(args.steps, 1)
-    hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "conv3x3_mfma_head", "out_head",
+    hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "conv3x3_mfma_head", "conv3x3_mfma_pair", "out_head",
                                                                        "first_conv", "conv1x1_mfma", "style")) / max(args.steps, 1)
     net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
     mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,

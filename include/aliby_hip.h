@@ -204,6 +204,18 @@ int aliby_nn_conv3x3_head_bf16(aliby_ctx* ctx, const void* in, const void* wpk, 
                                int N, int H, int W, int CIN, int COUT, const float* head_scale,
                                const float* head_shift, const float* head_w, const float* head_bias, int head_channels,
                                float* head_out, void* stream);
+/* Two consecutive 32 -> 32 units of a residual block in ONE launch (cellpose resdown / resup: x + conv3(conv2(x)),
+ * segment/unet.py): out = conv_b(act_b(conv_a(act_a(in)) + bias_a)) + bias_b + res, the tensor in between kept in LDS
+ * (rounded to bf16 where the two-launch path stores it: same bits as two aliby_nn_conv3x3_bf16 launches).  An 8-wave
+ * workgroup per CU: four waves hold unit A's weights and produce a tile's intermediate block while the other four hold
+ * unit B's and consume the previous tile's.  pool_out as in aliby_nn_conv3x3_bf16; head_* as in
+ * aliby_nn_conv3x3_head_bf16 (head_out != NULL: out_or_null may be NULL). */
+int aliby_nn_conv3x3_pair_bf16(aliby_ctx* ctx, const void* in, const void* wpk_a, const void* wpk_b, void* out_or_null,
+                               const float* scale_a, const float* shift_a, int shift_a_per_sample, const float* bias_a,
+                               const float* scale_b, const float* shift_b, int shift_b_per_sample, const float* bias_b,
+                               const void* res, int N, int H, int W, void* pool_out, const float* head_scale,
+                               const float* head_shift, const float* head_w, const float* head_bias, int head_channels,
+                               float* head_out, void* stream);
 /* float32 OIHW [COUT, CIN_src, 3, 3] device weights -> the MFMA fragment order the kernel above reads
  * ([COUT/32][9 taps][CIN/16][64 lanes][8] bf16, COUT*CIN*9*2 bytes; input channels >= CIN_src are zero). */
 int aliby_nn_pack_conv3x3_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN_src, int CIN, void* wpk,

@@ -173,6 +173,57 @@ def test_conv_unit_with_fused_output_head(engine, shape, O):
             assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 44, 70), (1, 10, 6), (5, 14, 30), (2, 16, 62), (1, 2, 2)])
+@pytest.mark.parametrize("mode", ["plain", "pool", "head", "head_keep"])
+def test_conv_pair_equals_two_launches(engine, shape, mode):
+    """The wave-specialised fused pair (aliby_nn_conv3x3_pair_bf16) against two aliby_nn_conv3x3_bf16 launches (and
+    aliby_nn_out_head_bf16 for the head variants), bit for bit, on tiles that do and do not divide by 14 x 30."""
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    n, H, W = shape
+    g = torch.Generator().manual_seed(n * 31 + H + len(mode))
+    x = torch.randn(n, H, W, 32, generator=g).to(torch.bfloat16).cuda()
+    pk, ws = [], []
+    for k in range(2):
+        w = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).float().cuda()
+        p = torch.empty(32 * 32 * 9, dtype=torch.bfloat16, device="cuda")
+        _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), 32, 32, 32, _ptr(p), _stream_ptr()))
+        pk.append(p)
+        ws.append(w)
+    sc = [(torch.rand(32, generator=g) + 0.5).float().cuda() for _ in range(2)]
+    sh = [(torch.randn(n, 32, generator=g) * 0.2).float().cuda(), (torch.randn(32, generator=g) * 0.2).float().cuda()]  # per image | shared
+    bi = [(torch.randn(32, generator=g) * 0.1).float().cuda() for _ in range(2)]
+    res = torch.randn(n, H, W, 32, generator=g).to(torch.bfloat16).cuda()
+    pool = mode == "pool" and H % 2 == 0 and W % 2 == 0
+    head = mode.startswith("head")
+    mid = _run(engine, x, ws[0], sc[0], sh[0], bi[0], None, False, False, H, W)
+    pooled2 = torch.full((n, H // 2, W // 2, 32), float("nan"), dtype=torch.bfloat16, device="cuda") if pool else None
+    want = _run(engine, mid, ws[1], sc[1], sh[1], bi[1], res, False, False, H, W, pool=pooled2)
+    hs, hb = (torch.rand(32, generator=g) + 0.5).float().cuda(), (torch.randn(32, generator=g) * 0.2).float().cuda()
+    hw, hbias = (torch.randn(3, 32, generator=g) * 0.3).float().cuda(), torch.randn(3, generator=g).float().cuda()
+    want_head = torch.full((n, 3, H, W), float("nan"), device="cuda")
+    if head:
+        _lib.check(engine.lib.aliby_nn_out_head_bf16(engine.ctx.handle, _ptr(want), _ptr(hs), _ptr(hb), _ptr(hw), _ptr(hbias), n, H, W, 32, 3,
+                                                     _ptr(want_head), _stream_ptr()))
+    out = torch.full_like(want, float("nan")) if mode != "head" else None
+    pooled1 = torch.full_like(pooled2, float("nan")) if pool else None
+    got_head = torch.full((n, 3, H, W), float("nan"), device="cuda")
+    _lib.check(engine.lib.aliby_nn_conv3x3_pair_bf16(
+        engine.ctx.handle, _ptr(x), _ptr(pk[0]), _ptr(pk[1]), _ptr(out) if out is not None else 0, _ptr(sc[0]), _ptr(sh[0]), 32, _ptr(bi[0]),
+        _ptr(sc[1]), _ptr(sh[1]), 0, _ptr(bi[1]), _ptr(res), n, H, W, _ptr(pooled1) if pool else 0,
+        _ptr(hs) if head else 0, _ptr(hb) if head else 0, _ptr(hw) if head else 0, _ptr(hbias) if head else 0, 3 if head else 0,
+        _ptr(got_head) if head else 0, _stream_ptr()))
+    torch.cuda.synchronize()
+    if out is not None:
+        assert torch.equal(out, want)
+    if pool:
+        assert torch.equal(pooled1, pooled2)
+    if head:
+        assert torch.equal(got_head, want_head)
+
+
 @pytest.mark.parametrize("cin,cout,in_up", COMBOS)
 def test_conv_unit_random_data_full_tile_shapes(engine, cin, cout, in_up):
     import torch

@@ -215,6 +215,15 @@ def test_fused_unet_matches_module_forward(engine):
     ya, _ = with_head(x)
     yb, _ = separate(x)
     assert torch.equal(ya, yb)
+    # ... and so does running conv2 + conv3 of the level-0 blocks as one wave-specialised launch or as two launches
+    unpaired = FusedUNet(net, engine)
+    unpaired.fused_pair = False
+    assert with_head.fused_pair
+    yc, sc_ = unpaired(x)
+    assert torch.equal(ya, yc)
+    unpaired.fused_head = False
+    yd, _ = unpaired(x)
+    assert torch.equal(ya, yd)
 
 
 def test_dynamics_large_mask_uses_global_scratch(engine):
