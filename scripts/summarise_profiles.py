@@ -49,6 +49,8 @@ if files:
               open(f"profiles/{tag}_launch_gaps.json", "w"), indent=1)
     # the bench's timing groups, from the same trace: what `roofline.avg_launch_ms` / `roofline_mfma.avg_launch_ms` must agree with
     def grp(k):
+        if k.startswith("k_conv_pair32"):
+            return "conv3x3_mfma_pair"
         if k.startswith("k_conv3x3"):
             params = k.split("(")[0].rstrip(">").split("<")[-1].split(", ")
             if k.startswith("k_conv3x3<") and len(params) == 8 and params[7] == "true":
@@ -85,6 +87,8 @@ for which, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         t = traffic.setdefault(k, {"FETCH_SIZE": [], "WRITE_SIZE": []})
         t[col].append(float(r["Counter_Value"]))
 def conv_group(k):  # same split as fused_unet._launch_unit / _unit_head: 128-output-channel launches are the compute-bound group
+    if k.startswith("k_conv_pair32"):
+        return "conv3x3_mfma_pair"
     if not k.startswith("k_conv3x3"):
         return None
     params = k.split("(")[0].rstrip(">").split("<")[-1].split(", ")
@@ -94,7 +98,7 @@ def conv_group(k):  # same split as fused_unet._launch_unit / _unit_head: 128-ou
 
 
 groups = {"conv3x3_mfma": lambda k: conv_group(k) == "conv3x3_mfma", "conv3x3_mfma_deep": lambda k: conv_group(k) == "conv3x3_mfma_deep",
-          "conv3x3_mfma_head": lambda k: conv_group(k) == "conv3x3_mfma_head",
+          "conv3x3_mfma_head": lambda k: conv_group(k) == "conv3x3_mfma_head", "conv3x3_mfma_pair": lambda k: conv_group(k) == "conv3x3_mfma_pair",
           "fused_pointwise": lambda k: k.startswith("k_fused_act"), "out_head": lambda k: k.startswith("k_out_head"),
           "conv1x1_mfma": lambda k: k.startswith("k_conv1x1"), "first_conv": lambda k: k.startswith("k_first_conv")}
 out = {}
