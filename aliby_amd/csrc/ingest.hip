@@ -105,8 +105,12 @@ struct Tiff {
       int ts = type_size(type);
       if (ts == 0) continue;
       size_t vo = eo + (big ? 12 : 8);
-      if (count * ts > (uint64_t)off_sz) vo = big ? u64(vo) : u32(vo);
+      if (count > (uint64_t)off_sz / ts) {  // out-of-line values: the multiply below cannot wrap once count <= n / ts
+        if (count > f.n / ts) { err = "tag data outside the file"; return false; }
+        vo = big ? u64(vo) : u32(vo);
+      }
       if (!in(vo, count * ts)) { err = "tag data outside the file"; return false; }
+      if (count == 0) continue;
       auto val = [&](uint64_t i) -> uint64_t {
         size_t o = vo + i * ts;
         switch (ts) { case 1: return f.p[o]; case 2: return u16(o); case 4: return u32(o); default: return u64(o); }
@@ -138,6 +142,21 @@ struct Tiff {
     return true;
   }
 
+  // Field ranges every later size computation relies on (each product below stays far inside 64 bits).
+  static bool validate(const Page& pg, std::string& err) {
+    const uint64_t DIM_MAX = 0x7fffffffull, BLOCK_MAX = 1ull << 33;
+    if (pg.width < 1 || pg.height < 1 || pg.width > DIM_MAX || pg.height > DIM_MAX) { err = "image width / height out of range"; return false; }
+    if (pg.spp < 1 || pg.spp > 64) { err = "SamplesPerPixel out of range: " + std::to_string(pg.spp); return false; }
+    if (pg.bits % 8 != 0 || pg.bits < 8 || pg.bits > 64) { err = "only 8/16/32/64-bit samples are supported, got " + std::to_string(pg.bits); return false; }
+    if (pg.planar != 1 && pg.planar != 2) { err = "PlanarConfiguration out of range"; return false; }
+    const uint64_t px = (uint64_t)pg.spp * (uint64_t)(pg.bits / 8);  // <= 512
+    if (pg.tiled) {
+      if (pg.tile_w < 1 || pg.tile_h < 1 || pg.tile_w > DIM_MAX || pg.tile_h > DIM_MAX) { err = "tile size out of range"; return false; }
+      if (pg.tile_w * pg.tile_h > BLOCK_MAX / px) { err = "tile larger than 8 GiB"; return false; }
+    } else if (pg.rows_per_strip * pg.width > BLOCK_MAX / px) { err = "strip larger than 8 GiB"; return false; }
+    return true;
+  }
+
   // full-resolution pages only (NewSubfileType bit 0 marks a reduced copy)
   bool page(int index, Page& pg, std::string& err) const {
     uint64_t off = first_ifd;
@@ -147,7 +166,11 @@ struct Tiff {
       uint64_t next;
       if (!read_ifd(off, &cur, next, err)) return false;
       if (!(cur.subfile & 1)) {
-        if (seen == index) { pg = std::move(cur); return true; }
+        if (seen == index) {
+          if (!validate(cur, err)) return false;
+          pg = std::move(cur);
+          return true;
+        }
         ++seen;
       }
       off = next;
@@ -326,6 +349,7 @@ size_t page_blocks(const Page& pg) {
 
 // Decodes blocks [b0, b1) of the page into the full-plane destination.
 bool decode_page(const Tiff& t, const Page& pg, uint8_t* dst, std::string& err, size_t b0, size_t b1) {
+  if (!Tiff::validate(pg, err)) return false;
   if (pg.bits % 8 != 0 || pg.bits < 8 || pg.bits > 64) { err = "only 8/16/32/64-bit samples are supported, got " + std::to_string(pg.bits); return false; }
   if (pg.predictor != 1 && pg.predictor != 2) { err = "floating-point predictor (3) is not supported"; return false; }
   if (pg.offsets.empty() || pg.offsets.size() != pg.counts.size()) { err = "strip/tile offsets and byte counts disagree"; return false; }
@@ -385,6 +409,7 @@ struct PinnedStage {
 // predictor, tiled, bigtiff, big_endian, uniform (every full-resolution page has page 0's geometry and sample type)
 int aliby_tiff_probe(const char* path, int64_t* info, char* description, int description_len) {
   ARG_CHECK(path && info, "path and info must be given");
+  try {
   std::string err;
   Tiff t;
   if (!t.open(path, err)) { aliby_set_error("%s", err.c_str()); return ALIBY_ERR_INVALID; }
@@ -412,6 +437,8 @@ int aliby_tiff_probe(const char* path, int64_t* info, char* description, int des
     snprintf(description, (size_t)description_len, "%s", first.description.c_str());
   }
   return ALIBY_OK;
+  } catch (const std::bad_alloc&) { aliby_set_error("%s: out of memory while reading the directory", path); return ALIBY_ERR_TOO_LARGE;
+  } catch (const std::exception& e) { aliby_set_error("%s: %s", path, e.what()); return ALIBY_ERR_INVALID; }
 }
 
 // Decode n planes (page `pages[i]` of `paths[i]`, sample 0) of width x height x bytes_per_sample into
@@ -419,9 +446,9 @@ int aliby_tiff_probe(const char* path, int64_t* info, char* description, int des
 // is decoded.  dst_is_device = 1: planes are decoded into the library's pinned staging block and each one is queued
 // for upload on `stream` the moment its decoder thread finishes, so PCIe transfers overlap the remaining decodes; the
 // call returns after the last upload has completed.
-int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int32_t* pages, int n, int width, int height,
-                             int bytes_per_sample, void* dst, size_t plane_stride, int dst_is_device, int n_threads,
-                             void* stream) {
+static int ingest_tiff_planes_impl(aliby_ctx* ctx, const char* const* paths, const int32_t* pages, int n, int width, int height,
+                                   int bytes_per_sample, void* dst, size_t plane_stride, int dst_is_device, int n_threads,
+                                   void* stream) {
   ARG_CHECK(n >= 0 && width > 0 && height > 0, "plane geometry");
   ARG_CHECK(bytes_per_sample == 1 || bytes_per_sample == 2 || bytes_per_sample == 4 || bytes_per_sample == 8, "bytes_per_sample");
   if (n == 0) return ALIBY_OK;
@@ -472,7 +499,7 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
       PlaneState& ps = *planes[k];
       std::string err;
       bool ok = ps.t.open(paths[i], err) && ps.t.page(pages ? pages[i] : 0, ps.pg, err);
-      if (ok && ((int)ps.pg.width != width || (int)ps.pg.height != height || ps.pg.bits != 8 * bytes_per_sample)) {
+      if (ok && (ps.pg.width != (uint64_t)width || ps.pg.height != (uint64_t)height || ps.pg.bits != 8 * bytes_per_sample)) {
         err = "geometry differs from the first file: " + std::to_string(ps.pg.width) + "x" + std::to_string(ps.pg.height) + "x" +
               std::to_string(ps.pg.bits) + " bits";
         ok = false;
@@ -492,6 +519,7 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
     std::vector<std::string> errors(threads);
     std::vector<hipError_t> hip_errors(threads, hipSuccess);
     auto worker = [&](int tid) {
+      try {  // nothing may unwind out of a std::thread (std::terminate) or across the C ABI
       if (dst_is_device) hip_errors[tid] = hipSetDevice(device);
       for (;;) {
         size_t w = next.fetch_add(1);
@@ -508,6 +536,10 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
         if (ps.remaining.fetch_sub(1) == 1 && dst_is_device && hip_errors[tid] == hipSuccess)
           hip_errors[tid] = hipMemcpyAsync((uint8_t*)dst + (size_t)i * plane_stride, host + (size_t)i * host_stride,
                                            plane_bytes, hipMemcpyHostToDevice, as_stream(stream));
+      }
+      } catch (const std::exception& e) {
+        errors[tid] = std::string("decoder failed: ") + e.what();
+        failed.store(1);
       }
     };
     if (threads == 1) worker(0);
@@ -530,9 +562,25 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
   return ALIBY_OK;
 }
 
+int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int32_t* pages, int n, int width, int height,
+                             int bytes_per_sample, void* dst, size_t plane_stride, int dst_is_device, int n_threads,
+                             void* stream) {
+  try {
+    return ingest_tiff_planes_impl(ctx, paths, pages, n, width, height, bytes_per_sample, dst, plane_stride, dst_is_device,
+                                   n_threads, stream);
+  } catch (const std::bad_alloc&) {
+    aliby_set_error("TIFF ingest: out of memory (implausible sizes in the file's directory?)");
+    return ALIBY_ERR_TOO_LARGE;
+  } catch (const std::exception& e) {
+    aliby_set_error("TIFF ingest: %s", e.what());
+    return ALIBY_ERR_INVALID;
+  }
+}
+
 // Chunk decompression for zarr stores: codec 0 = zlib / gzip, 1 = Zstandard.  *out_bytes = bytes produced.
 int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst, size_t dst_bytes, size_t* out_bytes) {
   ARG_CHECK(src && dst && out_bytes, "buffers must be given");
+  try {
   std::string err;
   size_t got = 0;
   bool ok;
@@ -542,4 +590,5 @@ int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst
   if (!ok) { aliby_set_error("%s", err.c_str()); return ALIBY_ERR_INVALID; }
   *out_bytes = got;
   return ALIBY_OK;
+  } catch (const std::exception& e) { aliby_set_error("inflate: %s", e.what()); return ALIBY_ERR_INVALID; }
 }

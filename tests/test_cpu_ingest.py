@@ -298,3 +298,64 @@ def test_inflate_entry_reports_corrupt_streams():
     with pytest.raises(Exception, match="Deflate"):
         _lib.check(lib.aliby_ingest_inflate(0, src.ctypes.data, src.size, out.ctypes.data, out.size, C.byref(got)))
 
+
+
+# ------------------------------------------------------------------------------------- hostile directory fields
+def _patch_tag(data: bytes, tag: int, value: int, dtype: int | None = None) -> bytes:
+    """Classic little-endian TIFF: overwrite the inline value (and optionally the type) of `tag` in the first IFD."""
+    import struct
+
+    b = bytearray(data)
+    assert b[:2] == b"II" and struct.unpack_from("<H", b, 2)[0] == 42
+    off = struct.unpack_from("<I", b, 4)[0]
+    n = struct.unpack_from("<H", b, off)[0]
+    for e in range(n):
+        eo = off + 2 + 12 * e
+        if struct.unpack_from("<H", b, eo)[0] == tag:
+            if dtype is not None:
+                struct.pack_into("<H", b, eo + 2, dtype)
+            struct.pack_into("<I", b, eo + 8, value & 0xFFFFFFFF)
+            return bytes(b)
+    raise KeyError(tag)
+
+
+_HOSTILE = [
+    ("plain_strips7", 277, 0, None),            # SamplesPerPixel 0: was a null-pointer memcpy (ADVICE r1)
+    ("plain_strips7", 277, 0xFFFF, None),
+    ("plain_strips7", 277, 0xFFFFFFFF, 4),
+    ("plain_tiles32x16", 322, 0x40000000, 4),   # TileWidth 2^30: was std::bad_alloc -> abort (ADVICE r1)
+    ("plain_tiles32x16", 323, 0x40000000, 4),
+    ("plain_tiles32x16", 322, 0, None),
+    ("plain_strips7", 258, 0, None),
+]
+
+
+@pytest.mark.parametrize("name,tag,value,dtype", _HOSTILE)
+def test_tiff_hostile_fields_are_refused_not_fatal(tmp_path, name, tag, value, dtype):
+    """One-field corruptions of the directory must come back as an error code through the C ABI: run in a child process so
+    that a crash (SIGSEGV / std::terminate) is a test failure rather than the end of the test session."""
+    import subprocess
+    import sys
+
+    good = (TIFFS / f"{name}.tif").read_bytes()
+    bad = tmp_path / "bad.tif"
+    bad.write_bytes(_patch_tag(good, tag, value, dtype))
+    info = im.tiff_info(TIFFS / f"{name}.tif")
+    code = (
+        "import sys, numpy as np, ctypes as C\n"
+        f"sys.path.insert(0, {str(Path(__file__).resolve().parents[1])!r})\n"
+        "from aliby_amd import _lib\n"
+        "lib = _lib.load()\n"
+        f"path = {str(bad)!r}.encode()\n"
+        "info = np.zeros(12, np.int64); desc = C.create_string_buffer(256)\n"
+        "rc0 = lib.aliby_tiff_probe(path, info.ctypes.data, desc, 256)\n"
+        f"w, h, bps = {info['width']}, {info['height']}, {info['bits'] // 8}\n"
+        "dst = np.zeros(w * h * bps, np.uint8)\n"
+        "paths = (C.c_char_p * 1)(path); pages = np.zeros(1, np.int32)\n"
+        "rc1 = lib.aliby_ingest_tiff_planes(None, paths, pages.ctypes.data, 1, w, h, bps, dst.ctypes.data, dst.size, 0, 2, None)\n"
+        "print('RC', rc0, rc1)\n"
+    )
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stderr[-800:])
+    rc0, rc1 = (int(x) for x in run.stdout.split("RC")[1].split())
+    assert rc0 != 0 and rc1 != 0  # both entry points refuse the page
