@@ -8,6 +8,12 @@ produces a NumPy result also registers the device tensor it came from; consumers
 the NumPy object up by identity and skip the host->device upload.  Entries vanish with
 the NumPy array (weakref), so the reference's end-of-tp `del entry["pixels"]`
 (pipe_core.py:238-242) also frees the device copy.
+
+Dirty check: a registered array is handed out READ-ONLY (`flags.writeable = False`).  An in-place edit between
+steps therefore raises NumPy's "assignment destination is read-only" instead of silently leaving a stale device
+copy behind; a caller who wants to edit either works on `arr.copy()` (a new object: never a cache hit) or flips
+`arr.flags.writeable = True` — and `lookup` treats a registered array found writeable as dirty, drops the entry
+and lets the consumer upload the host data again.
 """
 
 from __future__ import annotations
@@ -28,6 +34,10 @@ def attach(host_array, device_tensor, **meta):
         weakref.finalize(host_array, _drop)
     except TypeError:  # object does not support weak references
         return host_array
+    try:
+        host_array.flags.writeable = False
+    except (AttributeError, ValueError):
+        pass
     _table[key] = (ref, device_tensor, meta)
     return host_array
 
@@ -38,7 +48,7 @@ def lookup(host_array):
     if hit is None:
         return None
     ref, dev, meta = hit
-    if ref() is not host_array:
-        _table.pop(id(host_array), None)
+    if ref() is not host_array or getattr(getattr(host_array, "flags", None), "writeable", False):
+        _table.pop(id(host_array), None)  # another object at a recycled id, or the caller unlocked it to edit in place
         return None
     return dev, meta

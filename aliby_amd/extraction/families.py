@@ -40,6 +40,12 @@ class PlaneCache:
         if Z == 1 and op == _lib.RED_MAX:
             out, dt = self.tensor.reshape(F, C, Y, X), self.dtype
         else:
+            # np.add.reduce(uint16) is exact uint64 and np.divide.reduce float64 (distributors.py:22-24); the feature kernels
+            # read uint16 or float32 planes.  Sums of uint16 are exact in float32 while Z * 65535 < 2^24 (Z <= 256): beyond
+            # that the plane would silently lose bits, so it is refused.  "div" results carry float32 rounding (6e-8
+            # relative, three orders inside the 1e-4 feature tolerance).
+            if op == _lib.RED_ADD and self.dtype == _lib.U16 and Z * 65535 >= (1 << 24):
+                raise NotImplementedError(f"reduce_z 'add' over Z={Z} uint16 planes exceeds the exact float32 range (Z <= 256)")
             dt = self.dtype if op == _lib.RED_MAX else _lib.F32
             out = torch.empty((F, C, Y, X), dtype=torch.uint16 if dt == _lib.U16 else torch.float32,
                               device=self.tensor.device)
@@ -220,13 +226,26 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
                     "channel-combining multi instructions (extract.py:227-235) are not built; "
                     "the builder only emits red_ch='None' (pipe_builder.py:33-43)"
                 )
-            g = groups.setdefault(((ch0, ch1), red_z), dict(cols={}, thr=15.0, scale_max=255.0))
-            g["cols"][metric] = col0
-            g["thr"] = kw.get("thr", g["thr"])
-            g["scale_max"] = kw.get("scale_max", g["scale_max"])
+            # kwargs are per feature name, as the reference bakes them into one partial per name (loaders.py:71-77):
+            # manders_fold's thr must not leak into rwc.  The kernel takes one thr per launch, so metrics of a pair whose
+            # thresholds differ go to separate launches (sub-group key = the thr the launch will carry).
+            thr = float(kw.get("thr", 15.0)) if metric in ("manders_fold", "rwc") else None
+            scale_max = float(kw.get("scale_max", 255.0)) if metric == "costes" else None
+            groups.setdefault(((ch0, ch1), red_z), []).append((metric, col0, thr, scale_max))
+        split = {}
+        for key, entries in groups.items():
+            thrs = sorted({t for _, _, t, _ in entries if t is not None})
+            scale_max = next((sm for _, _, _, sm in entries if sm is not None), 255.0)
+            if len(thrs) <= 1:
+                split[(key, 0)] = dict(cols={m: c for m, c, _, _ in entries}, thr=thrs[0] if thrs else 15.0, scale_max=scale_max)
+            else:  # threshold-free metrics ride with the first threshold's launch
+                for k, t in enumerate(thrs):
+                    cols = {m: c for m, c, tt, _ in entries if tt == t or (tt is None and k == 0)}
+                    split[(key, k)] = dict(cols=cols, thr=t, scale_max=scale_max)
+        groups = {(pair_z, k): g for (pair_z, k), g in split.items()}
         if cache is None:
             raise Exception("pixels are required for colocalisation instructions")
-        for ((ch0, ch1), red_z), g in groups.items():  # shared inputs first, on the main stream: z-reduction, rank planes
+        for (((ch0, ch1), red_z), _k), g in groups.items():  # shared inputs first, on the main stream: z-reduction, rank planes
             plane, dt = cache.get(red_z)
             if "rwc" in g["cols"]:
                 eng.rank_planes(labels, plane, dt, table, (ch0, ch1))
@@ -234,7 +253,7 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
         import os
 
         batches = {}
-        for ((ch0, ch1), red_z), g in groups.items():
+        for (((ch0, ch1), red_z), _k), g in groups.items():
             batches.setdefault((red_z, g["thr"], g["scale_max"]), []).append(((ch0, ch1), g["cols"]))
         left = []
         for (red_z, thr, scale_max), pairs in batches.items():

@@ -294,37 +294,40 @@ class LazyArray:
         return out
 
 
+def _axis_names(ndim: int, capture_order: str, dimorder: str) -> list:
+    """Name of every source axis, outermost first.  `capture_order` names the innermost axes; further leading axes are
+    given the target dimensions `capture_order` does not mention, innermost-missing last, and None (anonymous) once those
+    run out.  A `capture_order` longer than the array loses its leading letters."""
+    named = list(capture_order[max(0, len(capture_order) - ndim):])
+    spare = [d for d in dimorder if d not in capture_order]
+    lead = ndim - len(named)
+    fill = spare[len(spare) - lead:] if lead <= len(spare) else [None] * (lead - len(spare)) + spare
+    return fill[:lead] + named if lead else named
+
+
 def adjust_dimensions(lazy, capture_order: str, dimorder: str):
-    """Bring an array whose axes are named by `capture_order` to `dimorder` (image.py:527-599): unnamed leading axes
-    take the missing dimension names from the end, axes outside `dimorder` must be of size one and are dropped, missing
-    ones are appended (in sorted order) and the result is permuted.  Accepts a LazyArray or a NumPy array."""
+    """Array whose innermost axes are named by `capture_order` -> axes in `dimorder` (contract of image.py:527-599, held by
+    tests/test_cpu_ingest.py::test_adjust_dimensions_*): axes the target does not have must be of length one and are
+    removed, target dimensions the source lacks become length-one axes, then one permutation.  LazyArray or NumPy in."""
     if not isinstance(lazy, LazyArray):
         lazy = LazyArray(ArraySource(lazy))
-    if lazy.ndim > len(capture_order):
-        missing = [d for d in dimorder if d not in capture_order]
-        n_extra = lazy.ndim - len(capture_order)
-        added = missing[-n_extra:] if n_extra <= len(missing) else missing
-        if len(added) < n_extra:
-            added = ["?"] * (n_extra - len(added)) + added
-        capture_order = "".join(added) + capture_order
-    elif lazy.ndim < len(capture_order):
-        capture_order = capture_order[-lazy.ndim :]
-    current = list(capture_order)
-    for i in range(len(current) - 1, -1, -1):
-        dim = current[i]
-        if dim not in dimorder:
-            assert lazy.shape[i] == 1, (
-                f"Dimension {dim} at index {i} has size {lazy.shape[i]}, "
-                f"but it is not in dimorder {dimorder} and thus must be 1 to be squeezed."
-            )
-            lazy = lazy.squeeze(i)
-            current.pop(i)
-    current = "".join(current)
-    for dim in sorted(d for d in dimorder if d not in current):
-        lazy = lazy.append_axis()
-        current += dim
-    assert len(current) == len(dimorder), f"Post-adjustment captureorder ({current}) and dimorder ({dimorder}) do not match."
-    return lazy.moveaxis([current.index(d) for d in dimorder], range(len(dimorder)))
+    names = _axis_names(lazy.ndim, capture_order, dimorder)
+    foreign = [axis for axis, name in enumerate(names) if name not in dimorder]
+    for axis in reversed(foreign):  # innermost first so the remaining indices stay valid
+        assert lazy.shape[axis] == 1, (
+            f"Dimension {names[axis] or '?'} at index {axis} has size {lazy.shape[axis]}, "
+            f"but it is not in dimorder {dimorder} and thus must be 1 to be squeezed."
+        )
+        lazy = lazy.squeeze(axis)
+    have = [name for name in names if name in dimorder]
+    for dim in dimorder:
+        if dim not in have:
+            lazy = lazy.append_axis()
+            have.append(dim)
+    assert len(have) == len(dimorder), (
+        f"Post-adjustment captureorder ({''.join(have)}) and dimorder ({dimorder}) do not match."
+    )
+    return lazy.moveaxis([have.index(dim) for dim in dimorder], range(len(dimorder)))
 
 
 # --------------------------------------------------------------------------------------------- TIFF helpers

@@ -171,6 +171,9 @@ def validate_pipeline(pipeline: dict) -> None:
             raise ValueError("Pipeline defines 'global_steps' but is missing 'global_passed_data'.")
         if not isinstance(pipeline["global_passed_data"], dict):
             raise TypeError("'global_passed_data' must be a dictionary.")
+        # well-formed but out of scope here (trackastra via Nahual): refused before any timepoint is
+        # processed, on the first run and on a resume alike
+        raise NotImplementedError("global steps (trackastra via Nahual) are out of scope (SURVEY §2 row 16)")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -261,6 +264,7 @@ def _run_pipeline_and_post_impl(pipeline: dict, pipeline_name: str, output_path,
     unless `overwrite` (resume-by-skip)."""
     output_path = Path(output_path)
     profiles_file = output_path / "profiles" / f"{pipeline_name}.parquet"
+    validate_pipeline(pipeline)  # before the resume check: a bad / out-of-scope dict fails the same way on every run
     if not overwrite and profiles_file.exists():
         logger.info(f"Skipping {pipeline_name}")
         return None, None
@@ -270,8 +274,6 @@ def _run_pipeline_and_post_impl(pipeline: dict, pipeline_name: str, output_path,
     pyarrow.parquet.write_table(profiles, profiles_file, compression="zstd")
     if post_state_hook is not None:
         post_state_hook(state, pipeline, output_path, pipeline_name)
-    if pipeline.get("global_steps"):
-        raise NotImplementedError("global steps (trackastra via Nahual) are out of scope (SURVEY §2 row 16)")
     return profiles, {}
 
 

@@ -12,8 +12,9 @@ through a linear layer before every up-convolution, 3 outputs = dY, dX, cell pro
 Pretrained weights are fetched from the network by the reference at model construction
 (src/aliby/segment/dispatch.py:171-175) and are NOT obtainable offline: without a
 `pretrained_model` file the module is randomly initialised with a fixed seed — good for throughput and
-MFMA-utilisation measurements, meaningless for masks.  The layer naming follows the public checkpoint
-layout closely enough that a state_dict of the same architecture can be loaded with `load_weights`.
+MFMA-utilisation measurements, meaningless for masks.  `load_cellpose_state_dict` maps the public CPnet checkpoint
+key layout (`downsample.down.res_down_k.…`, `upsample.up.res_up_k.…`, `make_style`, `output.…`, `diam_*`) onto this
+module's names; `build_network(pretrained_model=path)` uses it with a weights-only loader.
 """
 
 from __future__ import annotations
@@ -112,6 +113,62 @@ class ResidualUNet(nn.Module):
         return total
 
 
+# Public CPnet checkpoint layout (cellpose 2.x / 3.x `resnet_torch.CPnet`, nbase = [nchan, 32, 64, 128, 256], residual_on,
+# style_on, no concatenation; [UPSTREAM-RECALL], the package is not in this image) -> names of ResidualUNet:
+#   downsample.down.res_down_K.conv.conv_J.{0,2}.*        -> down.K.conv.J.{0,2}.*        (0 = BatchNorm, 2 = Conv)
+#   downsample.down.res_down_K.proj.{0,1}.*               -> down.K.proj.{0,1}.*          (0 = BatchNorm, 1 = 1x1 Conv)
+#   upsample.up.res_up_K.conv.conv_0.{0,2}.*              -> up.K.conv0.{0,2}.*
+#   upsample.up.res_up_K.conv.conv_J.conv.{0,2}.*  J=1..3 -> up.K.convJ.conv.{0,2}.*
+#   upsample.up.res_up_K.conv.conv_J.full.{weight,bias}   -> up.K.convJ.full.{weight,bias}
+#   upsample.up.res_up_K.proj.{0,1}.*                     -> up.K.proj.{0,1}.*
+#   output.{0,2}.*                                        -> output.{0,2}.*
+#   diam_mean, diam_labels                                -> returned separately (they rescale images, not weights)
+_CPNET_RULES = (
+    (r"^downsample\.down\.res_down_(\d+)\.conv\.conv_(\d+)\.(\d+)\.(\w+)$", r"down.\1.conv.\2.\3.\4"),
+    (r"^downsample\.down\.res_down_(\d+)\.proj\.(\d+)\.(\w+)$", r"down.\1.proj.\2.\3"),
+    (r"^upsample\.up\.res_up_(\d+)\.conv\.conv_0\.(\d+)\.(\w+)$", r"up.\1.conv0.\2.\3"),
+    (r"^upsample\.up\.res_up_(\d+)\.conv\.conv_([123])\.conv\.(\d+)\.(\w+)$", r"up.\1.conv\2.conv.\3.\4"),
+    (r"^upsample\.up\.res_up_(\d+)\.conv\.conv_([123])\.full\.(\w+)$", r"up.\1.conv\2.full.\3"),
+    (r"^upsample\.up\.res_up_(\d+)\.proj\.(\d+)\.(\w+)$", r"up.\1.proj.\2.\3"),
+    (r"^output\.(\d+)\.(\w+)$", r"output.\1.\2"),
+)
+_CPNET_EXTRA = ("diam_mean", "diam_labels")
+
+
+def cpnet_key_to_local(key: str) -> str | None:
+    """CPnet checkpoint key -> ResidualUNet key (None for the diameter buffers); KeyError for anything else."""
+    import re
+
+    key = key.removeprefix("module.")  # checkpoints saved from nn.DataParallel
+    if key in _CPNET_EXTRA:
+        return None
+    for pattern, repl in _CPNET_RULES:
+        if re.match(pattern, key):
+            return re.sub(pattern, repl, key)
+    raise KeyError(f"unrecognised CPnet checkpoint key: {key}")
+
+
+def load_cellpose_state_dict(net: "ResidualUNet", state: dict, strict: bool = True) -> dict:
+    """Load a state dict in the public CPnet key layout (or in this module's own layout) into `net`.
+
+    Returns {"diam_mean": float | None, "diam_labels": float | None}.  Shapes are checked by `load_state_dict`; a
+    checkpoint of another architecture (different nbase, concatenation=True, the 4.x transformer) fails there with the
+    offending keys named.  Call site replaced: CellposeModel(pretrained_model=...) at segment/dispatch.py:171-175."""
+    own = set(net.state_dict())
+    if all(k in own for k in state):
+        net.load_state_dict(state, strict=strict)
+        return {"diam_mean": None, "diam_labels": None}
+    mapped, extra = {}, {"diam_mean": None, "diam_labels": None}
+    for key, value in state.items():
+        local = cpnet_key_to_local(key)
+        if local is None:
+            extra[key.removeprefix("module.")] = float(torch.as_tensor(value).reshape(-1)[0])
+        else:
+            mapped[local] = value
+    net.load_state_dict(mapped, strict=strict)
+    return extra
+
+
 def build_network(seed: int = 0, pretrained_model: str | None = None, device="cuda") -> ResidualUNet:
     gen_state = torch.random.get_rng_state()
     torch.manual_seed(seed)
@@ -123,6 +180,6 @@ def build_network(seed: int = 0, pretrained_model: str | None = None, device="cu
             m.running_mean.zero_()
     torch.random.set_rng_state(gen_state)
     if pretrained_model is not None:
-        state = torch.load(pretrained_model, map_location="cpu", weights_only=True)
-        net.load_state_dict(state)
+        state = torch.load(pretrained_model, map_location="cpu", weights_only=True)  # executes nothing from the file
+        net.diam = load_cellpose_state_dict(net, state)
     return net.eval().to(device)

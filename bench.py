@@ -11,7 +11,7 @@ A "step" is one pass of the hot path over one batch of B FOVs per GPU, inputs re
 
     stage (crop/pad)                                                   HIP
     segment: Z-project -> normalize99 -> 224-px tiles                  HIP
-             -> residual U-Net forward                                 PyTorch-ROCm (MFMA via MIOpen)
+             -> residual U-Net forward (bf16, every conv hand-written) HIP (MFMA)
              -> taper blend                                            HIP
              -> dynamics (flow following, seeds, labels, QC, fill)     HIP
     extract: object table -> every feature family -> D2H of the rows   HIP

@@ -142,8 +142,9 @@ int aliby_average_tiles(aliby_ctx* ctx, const float* ytiles, int F, int Y, int X
  * optionally read through a 2x nearest upsample; act = relu?(scale[c]*sum + shift[n,c] or shift[c]).
  * shift_per_sample: 0 = one shift row for all samples, 1 = contiguous [N, C], >1 = row stride in floats.  SUM
  * and/or ACT are written.  Replaces the eager conv-bias / BatchNorm / ReLU / add / style-add / upsample
- * passes of the network that `model.eval` (segment/dispatch.py:208-215) runs; the convolutions themselves
- * stay in PyTorch-ROCm. */
+ * passes of the network that `model.eval` (segment/dispatch.py:208-215) runs.  Only the A/B fallback path
+ * (`FusedUNet(mfma_levels=())`, kept for the tests) uses it: the product forward runs the aliby_nn_conv* units
+ * below, which carry these stages in their prologue / epilogue. */
 int aliby_nn_fused_act_bf16(aliby_ctx* ctx, const void* A, const void* B, void* SUM, void* ACT,
                             const float* bias, const float* scale, const float* shift, int N, int H, int W,
                             int C, int upA, int upB, int relu, int shift_per_sample, void* stream);

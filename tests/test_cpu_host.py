@@ -283,3 +283,83 @@ def test_c_caller_links_against_the_header_and_fails_loudly_without_a_gpu(tmp_pa
     assert "abi 1" in out.stdout and "tiff pages=1 width=52 height=40 bits=16 compression=5" in out.stdout
     if not torch.cuda.is_available():
         assert out.returncode == 0 and "no context:" in out.stdout
+
+
+def test_global_steps_are_refused_before_any_work(tmp_path):
+    """A well-formed pipeline with global steps (out of scope) raises from validation — on the first run and on a resume —
+    instead of after the whole position has been processed."""
+    from aliby_amd import pipe, pipe_core
+
+    pipeline = {"steps": {"tile": {}}, "passed_data": {}, "global_steps": {"nahual_track": {"address": "ipc://x"}},
+                "global_passed_data": {"nahual_track": []}}
+    with pytest.raises(NotImplementedError, match="global steps"):
+        pipe_core.validate_pipeline(pipeline)
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "p.parquet").write_bytes(b"")
+    for overwrite in (True, False):
+        with pytest.raises(NotImplementedError, match="global steps"):
+            pipe.run_pipeline_and_post(pipeline, "p", tmp_path, overwrite=overwrite)
+    del pipeline["global_passed_data"]
+    with pytest.raises(ValueError, match="global_passed_data"):
+        pipe_core.validate_pipeline(pipeline)
+
+
+def test_devcache_hands_out_read_only_arrays_and_detects_unlocking():
+    """In-place edits of a cached step output cannot leave a stale device copy behind."""
+    from aliby_amd import devcache
+
+    host, dev = np.arange(12, dtype=np.uint16).reshape(3, 4), object()
+    out = devcache.attach(host, dev, kind="pixels")
+    assert out is host and devcache.lookup(host)[0] is dev
+    with pytest.raises(ValueError, match="read-only"):
+        host[0, 0] = 7
+    assert devcache.lookup(host.copy()) is None  # a copy is a new object
+    host.flags.writeable = True  # the caller opts into editing: the entry is dirty from now on
+    host[0, 0] = 7
+    assert devcache.lookup(host) is None and devcache.lookup(host) is None
+
+
+def test_cpnet_checkpoint_layout_loads(tmp_path):
+    """a6': a state dict in the public CPnet key layout (downsample.down.res_down_k..., upsample.up.res_up_k..., output,
+    diam_*) loads through build_network(pretrained_model=...) with a weights-only loader and gives the same forward
+    (VERDICT r1 'Missing' item 4).  The layout is restated from the published cellpose 2.x/3.x module: parity unpinned."""
+    import re
+
+    import torch
+
+    from aliby_amd.segment import unet
+
+    src = unet.build_network(seed=3, device="cpu")
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+
+    def to_cpnet(k):
+        k = re.sub(r"^down\.(\d+)\.conv\.(\d+)\.", r"downsample.down.res_down_\1.conv.conv_\2.", k)
+        k = re.sub(r"^down\.(\d+)\.proj\.", r"downsample.down.res_down_\1.proj.", k)
+        k = re.sub(r"^up\.(\d+)\.conv0\.", r"upsample.up.res_up_\1.conv.conv_0.", k)
+        k = re.sub(r"^up\.(\d+)\.conv([123])\.", r"upsample.up.res_up_\1.conv.conv_\2.", k)
+        k = re.sub(r"^up\.(\d+)\.proj\.", r"upsample.up.res_up_\1.proj.", k)
+        return k
+
+    ckpt = {to_cpnet(k): v.clone() for k, v in src.state_dict().items()}
+    assert "downsample.down.res_down_0.conv.conv_0.2.weight" in ckpt and "upsample.up.res_up_3.conv.conv_1.full.weight" in ckpt
+    assert "upsample.up.res_up_0.conv.conv_2.conv.0.running_mean" in ckpt and "output.2.bias" in ckpt
+    ckpt["diam_mean"] = torch.ones(1) * 17.0
+    ckpt["diam_labels"] = torch.ones(1) * 30.0
+    path = tmp_path / "cyto_like"
+    torch.save(ckpt, path)
+    net = unet.build_network(seed=0, pretrained_model=str(path), device="cpu")
+    assert net.diam == {"diam_mean": 17.0, "diam_labels": 30.0}
+    for k, v in src.state_dict().items():
+        assert torch.equal(net.state_dict()[k], v), k
+    x = torch.randn(1, 2, 32, 32)
+    with torch.no_grad():
+        assert torch.equal(net(x)[0], src(x)[0])
+    # DataParallel prefix, own layout, and a foreign key
+    unet.load_cellpose_state_dict(net, {"module." + k: v for k, v in ckpt.items()})
+    unet.load_cellpose_state_dict(net, src.state_dict())
+    with pytest.raises(KeyError, match="unrecognised CPnet"):
+        unet.load_cellpose_state_dict(net, {**ckpt, "encoder.patch_embed.proj.weight": torch.zeros(1)})
+    with pytest.raises(RuntimeError):  # another architecture: shapes are checked
+        unet.load_cellpose_state_dict(net, {**ckpt, "output.2.weight": torch.zeros(5, 32, 1, 1)})

@@ -149,7 +149,7 @@ def test_network_forward_runs_and_is_deterministic(engine):
     dP2, p2 = model.run_network(x)
     assert dP1.shape == (1, 2, 256, 256) and p1.shape == (1, 256, 256)
     assert torch.isfinite(dP1).all() and torch.isfinite(p1).all()
-    # MIOpen may pick a different algorithm between calls: repeatable to float32 rounding, not bitwise
+    # every kernel of the forward is deterministic (fixed tile->workgroup map, no atomics): the tolerance is slack, not need
     assert torch.allclose(dP1, dP2, atol=1e-4) and torch.allclose(p1, p2, atol=1e-4)
     assert model.net.flops_per_pixel() > 1e5
 
