@@ -32,6 +32,11 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
 
     from aliby_amd.segment.cellpose_hip import CellposeModel
 
+    # Extension (not in the reference): per_tile=True returns one label image per tile, the container BABY's parser hands
+    # the reference's engine (list of [Y,X] masks, extract.py:271-281), instead of collapsing the tile axis as a Z axis
+    # (dispatch.py:218-223: what the reference's cellpose branch does to a multi-tile batch).  The trap-tile time-lapse
+    # workload (BASELINE config 4: tiles -> segment -> track -> extract) needs it; default False = reference behaviour.
+    per_tile = bool(kwargs.get("per_tile", False))
     setup_params = dict(kwargs.get("setup_params", {}))
     gpu = setup_params.pop("gpu", True)
     device = setup_params.pop("device", None)
@@ -50,6 +55,12 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         plane = model.select_and_project(src, channel_to_segment)  # device [F,Y,X], max over Z if Z>1
         result = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=True, z_axis=None, **kw)
         labels_dev = result[0]  # device uint16 [F,Y,X] (or [Y,X] when F==1: "Cellpose squeezes dims")
+        if per_tile:
+            stack = labels_dev if labels_dev.ndim == 3 else labels_dev[None]
+            if max(model.last_counts, default=0) >= np.iinfo(np.uint16).max:
+                raise OverflowError(f"Segmentation produced {max(model.last_counts)} labels; uint16 cast unsafe.")
+            host = stack.cpu().numpy()
+            return [devcache.attach(host[k], stack[k], kind="labels") for k in range(host.shape[0])]
         if labels_dev.ndim == 3:
             # reference: labels.max(axis=0) then relabel_sequential (dispatch.py:218-223)
             labels_dev = model.max_project_and_relabel(labels_dev)

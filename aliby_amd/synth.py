@@ -228,3 +228,49 @@ def trap_image(seed: int = 11, shape=(512, 512), spacing: int = 128, first: int 
             bar = (np.abs(yy - (y - 14)) <= 3) & (np.abs(xx - x) <= 16)
             img[bar] += 4000
     return np.clip(img, 0, 65535).astype(np.uint16), centres
+
+
+def make_timelapse(T: int = 10, seed: int = 11, n_z: int = 5, max_step: int = 2, shape=(512, 512)):
+    """Config-4-shaped position: a trap grid (`trap_image`) with 1 -> 3 yeast-like cells per trap appearing and growing
+    over time, the whole sample drifting by an integer random walk of at most `max_step` px per timepoint, Z planes of one
+    channel with a mild focus fall-off.  Returns dict(pixels u16 [T,1,Z,Y,X], labels u16 [T,Y,X] (ground truth, full
+    frame, labels = 3*trap + cell + 1 renumbered densely per frame), shifts int [T,2] cumulative (dy, dx), centres)."""
+    base, centres = trap_image(seed=seed, shape=shape)
+    rng = np.random.default_rng(fov_seed(4, seed))
+    Y, X = shape
+    yy, xx = np.mgrid[0:Y, 0:X]
+    steps = rng.integers(-max_step, max_step + 1, size=(T, 2))
+    steps[0] = 0
+    shifts = np.cumsum(steps, axis=0)
+    n_traps = len(centres)
+    # per trap: three cell slots at 120 degrees around a point just below the trap, born at t = 0, T/3, 2T/3
+    ang0 = rng.uniform(0, 2 * np.pi, n_traps)
+    r0 = rng.uniform(6.0, 8.0, (n_traps, 3))
+    amp = rng.uniform(500.0, 900.0, (n_traps, 3))
+    births = np.array([0, max(1, T // 3), max(2, (2 * T) // 3)])
+    pixels = np.zeros((T, 1, n_z, Y, X), np.uint16)
+    labels = np.zeros((T, Y, X), np.uint16)
+    for t in range(T):
+        frame = base.astype(np.float64)
+        lab = np.zeros(shape, np.uint16)
+        nxt = 0
+        for k, (cy, cx) in enumerate(centres):
+            for j in range(3):
+                if t < births[j]:
+                    continue
+                r = r0[k, j] + 0.15 * (t - births[j])
+                a = ang0[k] + j * 2 * np.pi / 3
+                y0, x0 = cy + 6 + 13.0 * np.sin(a), cx + 13.0 * np.cos(a)
+                d2 = (yy - y0) ** 2 + (xx - x0) ** 2
+                m = (d2 <= r * r) & (lab == 0)
+                if not m.any():
+                    continue
+                nxt += 1
+                lab[m] = nxt
+                frame[m] += amp[k, j] * np.sqrt(np.clip(1.0 - d2[m] / (r * r), 0, 1))
+        frame = np.roll(frame, tuple(shifts[t]), axis=(0, 1))
+        labels[t] = np.roll(lab, tuple(shifts[t]), axis=(0, 1))
+        for z in range(n_z):
+            plane = frame * (1.0 - 0.04 * abs(z - n_z // 2)) + rng.normal(0, 10.0, shape)
+            pixels[t, 0, z] = np.clip(plane, 0, 65535).astype(np.uint16)
+    return dict(pixels=pixels, labels=labels, shifts=shifts, centres=centres)

@@ -87,6 +87,10 @@ class Tiler:
         self._dev_stack = {}  # tp -> device [C,Z,Y,X] (keeps the last two, like load_image's lru_cache(2))
         self._engine = None
         self._ingest_stream = self._ingest_pool = self._ingest_pending = None
+        # The reference reads `calculate_drift` as an attribute a caller sets after construction (tiler.py:428-431); a
+        # pipeline dict has no way to do that, so the step parameter of the same name is accepted here.
+        if "calculate_drift" in kwargs:
+            self.calculate_drift = bool(kwargs["calculate_drift"])
 
     @classmethod
     def from_image(cls, image, parameters, **kwargs):

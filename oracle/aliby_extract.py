@@ -134,7 +134,7 @@ def extract_tree_multi(tileid_instructions, masks, pixels, cp_measure_kwargs=Non
     return result
 
 
-def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, limit=None, max_objects=None):
+def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, limit=None, max_objects=None, objects=None):
     if not isinstance(masks, list):
         masks = [masks]
     instructions = kv(flatten(tree))
@@ -145,6 +145,9 @@ def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, 
                 ind_masks.append((tile_i, mask_i))
     if max_objects is not None:  # bounded sample for the cpu_baseline leg of bench.py
         ind_masks = ind_masks[:max_objects]
+    if objects is not None:  # fixed subsample [(tile, label), ...] for full-size parity tests
+        wanted = set(map(tuple, objects))
+        ind_masks = [o for o in ind_masks if o in wanted]
     tileid_instructions = tuple(product(ind_masks, instructions))
     result = measure_fn(tileid_instructions, masks, pixels, cp_measure_kwargs=cp_measure_kwargs, limit=limit)
     return tileid_instructions, result

@@ -1,0 +1,292 @@
+"""
+BASELINE.json's configurations exercised AS configurations on the GPU (VERDICT r1 "Next round" 1a/1b), through the step
+API and the C ABI, against the CPU oracle:
+
+  * C2-shaped: one 1024x1024, 5-channel FOV with ~256 nuclei, the builder's full default mono + multi trees through
+    build_pipeline_steps -> run_pipeline_and_post; a fixed subsample of objects against the oracle at 1e-4, every object
+    through size-independent properties (finite values, Area == bincount, row order, label image bit-exact);
+  * C4-shaped: a 512x512, Z=5 time-lapse with a drifting trap grid: trap detection + drift + per-tile segmentation + IoU
+    tracking + sizeshape/intensity in ONE pipeline, T = 10, checked against the oracle and the committed trap fixture
+    (tests/golden/reference_traps.json = outputs of the reference's own segment_traps);
+  * the reference's own analytic tests (tests/extraction/test_volume.py:32-74: discs / ellipses within 1 % of closed form),
+    driven directly at aliby_features_cell;
+  * per-metric colocalisation kwargs.
+"""
+
+import json
+from copy import deepcopy
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from aliby_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+
+
+# ----------------------------------------------------------------------------------------------------------- C2
+def test_config2_full_default_tree_1024_5ch(tmp_path, engine):
+    import pyarrow.parquet
+    import torch
+
+    from aliby_amd.extraction.extract import format_extraction
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+    from oracle import aliby_extract as ox
+    from oracle import cellpose_restated as cr
+
+    f = synth.make_fov(2, 0)  # 5 x 1 x 1024 x 1024, ~250 nuclei
+    assert f["pixels"].shape == (5, 1, 1024, 1024)
+    dP, prob = synth.analytic_flows(f["nuclei"])
+    pipeline = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1, 2, 3, 4])
+    trees = {k: deepcopy(pipeline["steps"][k]["tree"]) for k in ("extract_nuclei", "extractmulti_nuclei")}
+    pipeline["steps"]["tile"]["image_kwargs"] = {"source": f["pixels"][None]}
+    pipeline["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(
+        flows_override=lambda x: (torch.from_numpy(dP[None]).cuda(), torch.from_numpy(prob[None]).cuda()))
+    profiles, _ = run_pipeline_and_post(pipeline=pipeline, pipeline_name="C2__0", output_path=tmp_path)
+
+    # ---- segmentation: label image bit-exact vs the oracle's dynamics
+    want_mask = cr.finish_labels(cr.compute_masks(dP, prob))
+    with np.load(tmp_path / "steps" / "C2__0" / "segment_nuclei" / "0000.npz") as z:
+        got_mask = z["arr_0"]
+    assert np.array_equal(got_mask, want_mask)
+    n = int(want_mask.max())
+    assert 200 <= n <= 300
+
+    # ---- table shape: 4 metadata + sizeshape + 5 x the six per-channel families + 10 pairs x 8 colocalisation keys
+    per_channel = 60 + 21 + 2 + 52 + 12 + 30
+    assert len(profiles.column_names) == 4 + 78 + 5 * per_channel + 10 * 8 == 1047
+    assert profiles.num_rows == n
+    got = profiles.to_pandas()
+    assert got["metadata_label"].tolist() == list(range(1, n + 1))  # first-seen (tile, label) row order
+    assert (got["metadata_tile"] == 0).all() and (got["metadata_object"] == "nuclei").all() and (got["metadata_tp"] == 0).all()
+    assert pyarrow.parquet.read_table(tmp_path / "profiles" / "C2__0.parquet").equals(profiles)
+
+    # ---- every object: size-independent properties
+    area = np.bincount(want_mask.ravel())[1:]
+    assert np.array_equal(got["None/None/sizeshape/Area"].to_numpy(), area.astype(float))
+    values = got.drop(columns=["metadata_object"]).to_numpy(float)
+    assert np.isfinite(values).mean() > 0.999  # NaN only where a definition is undefined (e.g. a texture direction with no pairs)
+    for c in range(5):
+        px = f["pixels"][c, 0].astype(np.float64)
+        tot = np.bincount(want_mask.ravel(), weights=px.ravel())[1:]
+        assert np.allclose(got[f"{c}/max/intensity/Intensity_IntegratedIntensity"].to_numpy(), tot, rtol=1e-12)
+        for metric, keys in (("manders_fold", ("Manders_1", "Manders_2")), ("rwc", ("RWC_1", "RWC_2")), ("costes", ("Costes_1", "Costes_2"))):
+            for c1 in range(c + 1, 5):
+                for key in keys:
+                    v = got[f"({c}, {c1})/None/max/{metric}/Correlation_{key}"].to_numpy()
+                    assert ((v >= 0) & (v <= 1 + 1e-12)).all(), (c, c1, key)
+
+    # ---- a fixed subsample of objects against the oracle run in the reference's structure (per-object full-frame masks)
+    sample = sorted({1, 2, n // 5, n // 3, n // 2, (2 * n) // 3, n - 1, n})
+    objects = [(0, l) for l in sample]
+    pixels = f["pixels"][None]
+    t1 = format_extraction(ox.process_tree_masks(trees["extract_nuclei"], want_mask, pixels, ox.extract_tree, objects=objects))
+    t2 = format_extraction(ox.process_tree_masks(trees["extractmulti_nuclei"], want_mask, pixels, ox.extract_tree_multi,
+                                                 objects=objects))
+    want = t1.to_pandas().merge(t2.to_pandas(), on=["tile", "label"]).set_index("label").sort_index()
+    assert want.index.tolist() == sample
+    sub = got.set_index("metadata_label").loc[sample]
+    assert set(want.columns) - {"tile"} == set(got.columns) - {"metadata_tile", "metadata_label", "metadata_object", "metadata_tp"}
+    worst = 0.0
+    for col in want.columns:
+        if col == "tile":
+            continue
+        a, b = sub[col].to_numpy(float), want[col].to_numpy(float)
+        if col.endswith("Orientation"):
+            flip = np.isclose(np.abs(a), 45.0) & np.isclose(np.abs(b), 45.0)
+            a, b = a[~flip], b[~flip]
+        if "ZernikePhase" in col:  # a phase is defined modulo 2 pi, and undefined where the magnitude vanishes
+            mag = sub[col.replace("Phase", "Magnitude")].to_numpy(float)
+            d = np.abs(np.angle(np.exp(1j * (a - b))))
+            assert (d[mag > 1e-9] < 1e-4).all(), col
+            continue
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-8, equal_nan=True), (col, a, b)  # north_star: float features within 1e-4 rel
+        ok = np.isfinite(a) & np.isfinite(b) & (np.abs(b) > 1e-6)
+        if ok.any():
+            worst = max(worst, float(np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok]))))
+    print(f"C2 parity: {len(sample)} objects x {len(want.columns) - 1} columns, worst relative error {worst:.2e}")
+
+
+# ----------------------------------------------------------------------------------------------------------- C4
+def test_config4_traps_drift_track_extract_in_one_pipeline(tmp_path, engine):
+    import torch
+
+    from aliby_amd.extraction.extract import format_extraction
+    from aliby_amd.pipe import init_step
+    from aliby_amd.pipe_core import get_profiles_from_state, run_pipeline_return_state
+    from oracle import aliby_extract as ox
+    from oracle import cellpose_restated as cr
+    from oracle import tiler_ref
+    from oracle.drift_restated import phase_cross_correlation as oracle_pcc
+    from oracle.track_restated import stitch_rois as oracle_rois
+    from oracle.traps_restated import segment_traps as oracle_traps
+
+    T, tile, half = 10, 117, 117 // 2
+    tl = synth.make_timelapse(T=T, seed=11)
+    frames = tl["pixels"]  # [T,1,5,512,512]
+
+    # ---------------- oracle side: trap centres, drifts, windows, per-tile masks, tracks, features
+    fixture = json.loads((G / "reference_traps.json").read_text())["cases"][0]
+    assert fixture["seed"] == 11 and fixture["tile_size"] == tile
+    found = [tuple(int(v) for v in c) for c in oracle_traps(frames[0, 0, 0], tile)]
+    assert found == [tuple(c) for c in fixture["segment_traps"]]  # the reference's own segment_traps output, cells or not
+    centres = [c for c in found if half < c[0] < 512 - half and half < c[1] < 512 - half]
+    assert len(centres) == 9
+    drifts, o_pixels, o_masks, o_flows = [], [], [], []
+    for t in range(T):
+        drifts.append(oracle_pcc(frames[max(0, t - 1), 0, 0], frames[t, 0, 0]).tolist())
+        cum = np.sum(drifts, axis=0)
+        ranges = []
+        for cy, cx in centres:
+            y, x = (np.array([cy, cx]) - cum).astype(int)
+            ranges.append((slice(int(y) - half, int(y) - half + tile), slice(int(x) - half, int(x) - half + tile)))
+        assert all(r[0].start >= 0 and r[1].start >= 0 and r[0].stop <= 512 and r[1].stop <= 512 for r in ranges)
+        o_pixels.append(tiler_ref.get_fczyx(frames[t], ranges))  # [9,1,5,117,117]
+        gt = [tl["labels"][t][r] for r in ranges]
+        flows = [synth.analytic_flows(tiler_ref.relabel_sequential(g)) for g in gt]
+        o_flows.append((np.stack([fl[0] for fl in flows]), np.stack([fl[1] for fl in flows])))
+        o_masks.append([cr.finish_labels(cr.compute_masks(*fl)) for fl in flows])
+    assert np.array_equal(np.array(drifts[1:]), -np.diff(tl["shifts"], axis=0).astype(float))  # the walk that was applied
+    tree = {"None": {"None": ["sizeshape"]}, 0: {"max": ["intensity"]}}
+
+    # ---------------- GPU side: ONE pipeline dict through the engine
+    calls = {"n": 0}
+
+    def override(x):  # x: device uint16 [F,117,117] = max over Z of the tile stack of this timepoint
+        t = calls["n"]
+        calls["n"] += 1
+        assert np.array_equal(x.cpu().numpy(), o_pixels[t][:, 0].max(axis=1)), f"tile windows differ at tp {t}"
+        return torch.from_numpy(o_flows[t][0]).cuda(), torch.from_numpy(o_flows[t][1]).cuda()
+
+    pipeline = {
+        "ntps": T,
+        "steps": {
+            "tile": {"image_kwargs": {"source": frames}, "tile_size": tile, "ref_channel": 0, "calculate_drift": True},
+            "segment_cells": {"segmenter_kwargs": {"kind": "cellpose", "per_tile": True, "setup_params": {"flows_override": override}},
+                              "channel_to_segment": 0},
+            "track": {"kind": "stitch", "stitch_threshold": 0.25},
+            "extract_cells": {"tree": tree},
+        },
+        "passed_data": {"track": [("masks", "segment_cells"), ("track_info", "track")],
+                        "extract_cells": [("masks", "segment_cells"), ("pixels", "tile")]},
+        "passed_methods": {"segment_cells": ("tile", "get_fczyx")},
+        "save": ("segment_cells",),
+        "save_interval": 1,
+        "retain": {"tile": 1, "segment_cells": 2},
+    }
+    state = run_pipeline_return_state(pipeline, tmp_path / "steps" / "pos", init_step)
+    assert calls["n"] == T
+    tiler = state["fn"]["tile"]
+    assert [list(map(int, c)) for c in tiler.tile_locs.initial_location] == [list(c) for c in centres]
+    assert tiler.tile_locs.drifts == drifts
+
+    # masks written per timepoint: a list result goes through np.asarray -> one stacked `arr_0` (write.py:25-51)
+    for t in range(T):
+        with np.load(tmp_path / "steps" / "pos" / "segment_cells" / f"{t:04d}.npz") as z:
+            assert list(z.keys()) == ["arr_0"] and z["arr_0"].shape == (9, tile, tile)
+            for k in range(9):
+                assert np.array_equal(z["arr_0"][k], o_masks[t][k]), (t, k)
+
+    # tracks: same state machine as the engine's wiring, on the oracle's masks
+    info = None
+    for t in range(T):
+        if t == 0:
+            want = {k: {"labels": list(range(1, int(o_masks[0][k].max()) + 1)), "max_label": int(o_masks[0][k].max())} for k in range(9)}
+        else:
+            want = oracle_rois([[o_masks[t - 1][k], o_masks[t][k]] for k in range(9)], info)
+        assert dict(state["data"]["track"][t]) == want, t
+        info = want
+    # cells are born, none vanish and the tiles follow the sample: identities persist, new cells get new ids
+    last = state["data"]["track"][-1]
+    assert all(sorted(last[k]["labels"]) == list(range(1, last[k]["max_label"] + 1)) for k in range(9))
+    assert all(last[k]["max_label"] == 3 for k in range(9))
+
+    # features
+    profiles = get_profiles_from_state(state, pipeline).to_pandas()
+    assert sorted(profiles["metadata_tp"].unique().tolist()) == list(range(T))
+    for t in range(T):
+        want = format_extraction(ox.process_tree_masks(tree, o_masks[t], o_pixels[t], ox.extract_tree)).to_pandas()
+        sub = profiles[profiles["metadata_tp"] == t]
+        assert sub[["metadata_tile", "metadata_label"]].to_numpy().tolist() == want[["tile", "label"]].to_numpy().tolist()
+        for col in want.columns:
+            if col in ("tile", "label") or col.endswith("Orientation"):
+                continue
+            assert np.allclose(sub[col].to_numpy(float), want[col].to_numpy(float), rtol=1e-4, atol=1e-8, equal_nan=True), (t, col)
+
+
+# --------------------------------------------------------------------------------- the reference's analytic cell.py tests
+def _ellipse(x, y, rotate):
+    """Pixels strictly inside the rotated ellipse of semi-axes (x rows, y cols) centred in a (4x, 4y) frame."""
+    rr, cc = np.mgrid[: 4 * x, : 4 * y].astype(np.float64)
+    r, c = rr - 2 * x, cc - 2 * y
+    phi = np.deg2rad(rotate) % np.pi
+    a = (r * np.cos(phi) + c * np.sin(phi)) / x
+    b = (r * np.sin(phi) - c * np.cos(phi)) / y
+    return a * a + b * b < 1
+
+
+def test_reference_volume_tests_on_the_gpu_kernel(engine):
+    """tests/extraction/test_volume.py:32-74 (the only numeric assertions the reference holds on this path): volume of
+    discs and rotated ellipses, min/maj axis approximation and eccentricity, with the reference's own thresholds and
+    parametrisation (9 radii x 9 eccentricities x 9 rotations + 9 discs), evaluated by aliby_features_cell through the C ABI."""
+    from aliby_amd.extraction.engine import to_device_u16
+
+    threshold = 0.01
+    radii = list(range(10, 100, 10))
+    eccentricities = np.arange(0, 0.9, 0.1)
+    rotations = [10, 20, 30, 40, 50, 60, 70, 80, 90]
+    cols = {n: engine.CELL_COLUMNS.index(n) for n in ("volume", "min_ax", "maj_ax", "eccentricity", "area")}
+    n_cases = 0
+    for x in radii:
+        cases = [(x, int(np.round(np.sqrt(x**2 / (1 - ecc**2)))), rot) for ecc in eccentricities for rot in rotations]
+        H, W = 4 * x, 4 * max(c[1] for c in cases)
+        stack = np.zeros((len(cases) + 1, max(H, 2 * x + 1), max(W, 2 * x + 1)), np.uint16)
+        for k, (xx, yy, rot) in enumerate(cases):
+            stack[k, : 4 * xx, : 4 * yy] = _ellipse(xx, yy, rot)
+        gy, gx = np.mgrid[-x : x + 1, -x : x + 1]
+        stack[-1, : 2 * x + 1, : 2 * x + 1] = gx * gx + gy * gy <= x * x  # skimage.morphology.disk(x)
+        dl = to_device_u16(stack)
+        tab = engine.object_table(dl)
+        assert tab.n_obj == len(cases) + 1
+        out = engine.cell_metrics(dl, None, 0, 0, tab).cpu().numpy()
+        assert np.array_equal(out[:, cols["area"]], stack.reshape(len(stack), -1).sum(1).astype(float))
+        for k, (xx, yy, rot) in enumerate(cases):
+            v, mn, mj, e = (out[k, cols[n]] for n in ("volume", "min_ax", "maj_ax", "eccentricity"))
+            real_v = 4 * np.pi * xx * yy * xx / 3
+            assert abs(v - real_v) / real_v < threshold, (xx, yy, rot, v, real_v)  # test_volume_ellipsoid
+            assert np.allclose([mn, mj], [xx, yy], rtol=threshold * min(xx, yy)), (xx, yy, rot, mn, mj)  # test_approximation
+            real_ecc = np.sqrt(yy**2 - xx**2) / yy
+            assert np.isclose(real_ecc, e, rtol=threshold * real_ecc), (xx, yy, rot, e, real_ecc)  # test_roundness
+            n_cases += 3
+        real_v = 4 * np.pi * x**3 / 3
+        assert abs(out[-1, cols["volume"]] - real_v) / real_v < threshold  # test_volume_circular
+        n_cases += 1
+    assert n_cases == 2196  # the count the reference's own run reports
+
+
+# --------------------------------------------------------------------------------- per-metric colocalisation kwargs
+def test_coloc_kwargs_are_per_metric(engine):
+    """cp_measure_kwargs={'manders_fold': {'thr': 30}} must leave rwc at its default thr=15 (loaders.py:71-77 bakes kwargs
+    into one partial per feature name); both thresholds in one tree."""
+    from aliby_amd.extraction.extract import extract_tree_multi, process_tree_masks
+    from oracle import aliby_extract as ox
+
+    f = synth.make_fov(1, 3, shape=(256, 256), n_channels=3, n_target=20)
+    labels, pixels = f["nuclei"], f["pixels"][None]
+    tree = {(0, 1): {"None": {"max": ["pearson", "manders_fold", "rwc", "costes"]}},
+            (1, 2): {"None": {"max": ["manders_fold", "rwc"]}}, (0, 2): {"None": {"max": ["rwc"]}}}
+    for kw in ({"manders_fold": {"thr": 30}}, {"rwc": {"thr": 40}, "manders_fold": {"thr": 5}}, {}):
+        inst, res = process_tree_masks(tree, labels, pixels, extract_tree_multi, cp_measure_kwargs=kw)
+        inst_o, res_o = ox.process_tree_masks(tree, labels, pixels, ox.extract_tree_multi, cp_measure_kwargs=kw)
+        assert inst == inst_o and len(res) == len(res_o)
+        for a, b in zip(res, res_o):
+            for k in b:
+                assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-9, equal_nan=True), (kw, k)
+    # and the two settings really differ on this data
+    a = process_tree_masks(tree, labels, pixels, extract_tree_multi, cp_measure_kwargs={"manders_fold": {"thr": 60}})[1]
+    b = process_tree_masks(tree, labels, pixels, extract_tree_multi, cp_measure_kwargs={})[1]
+    assert any(not np.allclose(x["Correlation_Manders_1"], y["Correlation_Manders_1"]) for x, y in zip(a, b) if "Correlation_Manders_1" in x)
+    assert all(np.allclose(x["Correlation_RWC_1"], y["Correlation_RWC_1"]) for x, y in zip(a, b) if "Correlation_RWC_1" in x)
