@@ -92,9 +92,12 @@ class _Download:
     def __init__(self, event, views):
         self.event, self.views = event, views
 
-    def wait(self):
-        while not self.event.query():  # polled (see aliby_wait_stream): no late wake-up
-            pass
+    def wait(self, spin: bool = True):
+        if spin:
+            while not self.event.query():  # polled (see aliby_wait_stream): no late wake-up
+                pass
+        else:
+            self.event.synchronize()  # blocking, GIL released: for writer threads, where a late wake-up costs nothing
         return [v.numpy() for v in self.views]
 
 
@@ -164,8 +167,10 @@ class FeatureEngine:
         with torch.cuda.stream(side):
             for i, t in enumerate(tensors):
                 key = (slot, i, t.dtype)
-                buf = pool.get(key)
-                if buf is None or buf.numel() < t.numel():
+                buf = pool.get(key) if slot is not None else None
+                if slot is None:  # a buffer of its own (readers on other threads keep it alive; torch recycles pinned blocks)
+                    buf = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
+                elif buf is None or buf.numel() < t.numel():
                     buf = pool[key] = torch.empty(int(t.numel() * 1.25) + 1024, dtype=t.dtype, pin_memory=True)
                 v = buf[: t.numel()].view(t.shape)
                 v.copy_(t, non_blocking=True)

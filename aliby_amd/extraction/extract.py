@@ -38,6 +38,9 @@ REDUCTION_FUNS = {"max": "max", "mean": None, "median": None, "div": "div", "add
 from aliby_amd.extraction import families  # noqa: E402
 
 
+PRODUCT_TYPES = (tuple, list)  # containers of (object, instruction) pairs the columnar pivot accepts (runner.py adds a lazy one)
+
+
 def flatten(d: dict, pref=()) -> dict:
     """Nested dict -> {path: leaf} (extract.py:33-57)."""
     return reduce(
@@ -62,11 +65,17 @@ class DeviceResults(Sequence):
     """
 
     def __init__(self, matrix, objects, instructions, blocks, pairs=None):
-        self.matrix = matrix            # np.float64 [n_obj, n_cols]
+        self._matrix = matrix           # np.float64 [n_obj, n_cols], or a handle with .get() while the rows are in flight
         self.objects = objects          # [(tile, label), ...] row order
         self.instructions = instructions  # distinct instruction tuples, column-block order
         self.blocks = blocks            # per instruction: (col_start, [key, ...] or None for scalar)
         self._pairs = pairs             # optional explicit [(row, inst_index)] when not a full product
+
+    @property
+    def matrix(self):
+        if not isinstance(self._matrix, np.ndarray):
+            self._matrix = self._matrix.get()  # rows downloaded on a side stream (aliby_amd/runner.py): wait for them now
+        return self._matrix
 
     def __len__(self):
         if self._pairs is not None:
@@ -245,7 +254,7 @@ def format_extraction(instructions_result) -> pa.Table:
     """(instructions, results) -> wide pyarrow table (extract.py:520-599)."""
     if isinstance(instructions_result, (tuple, list)) and len(instructions_result) == 2:
         inst, res = instructions_result
-        if isinstance(res, DeviceResults) and res._pairs is None and isinstance(inst, (tuple, list)):
+        if isinstance(res, DeviceResults) and res._pairs is None and isinstance(inst, PRODUCT_TYPES):
             if len(inst) != len(res):
                 raise ValueError("zip() argument 2 is shorter than argument 1" if len(res) < len(inst)
                                  else "zip() argument 2 is longer than argument 1")

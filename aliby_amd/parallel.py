@@ -74,3 +74,10 @@ def gather_rows(values: torch.Tensor, meta: torch.Tensor, dst: int = 0, group=No
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+def run_positions(pipelines, names, output_path, **kwargs):
+    """Many positions behind the step API, B per device step, sharded i % world == rank: see aliby_amd/runner.py."""
+    from aliby_amd.runner import run_positions as _run
+
+    return _run(pipelines, names, output_path, **kwargs)

@@ -133,11 +133,18 @@ class CellposeModel:
             dev = pixels.to(self.device)
         else:
             pixels = np.ascontiguousarray(pixels)
-            if pixels.dtype != np.uint16:
-                raise NotImplementedError(f"the HIP segmentation path handles uint16 pixels, got {pixels.dtype}")
+            if pixels.dtype in (np.uint8, np.bool_):
+                pixels = pixels.astype(np.uint16)
+            elif pixels.dtype != np.uint16:
+                pixels = pixels.astype(np.float32)
             dev = torch.from_numpy(pixels).to(self.device)
         dev = dev.contiguous()
         F, C, Z, Y, X = dev.shape
+        if dev.dtype != torch.uint16:
+            # float stacks (not produced by any of the reference's fixtures, which are uint16: SURVEY §3.3): the select and
+            # the Z maximum are two strided reads, done with device tensor ops rather than a dedicated kernel
+            dev = dev.to(torch.float32)
+            return (dev[:, int(channel)].amax(dim=1) if Z > 1 else dev[:, int(channel), 0]).contiguous()
         out = torch.empty((F, Y, X), dtype=torch.uint16, device=self.device)
         with self.eng.timed("select_project"):
             _lib.check(self.eng.lib.aliby_select_project_u16(self.eng.ctx.handle, _ptr(dev), F, C, Z, Y, X, int(channel),
@@ -179,6 +186,8 @@ class CellposeModel:
 
     def normalize(self, img_u16: torch.Tensor) -> torch.Tensor:
         F, Y, X = img_u16.shape
+        if img_u16.dtype != torch.uint16:
+            return self._normalize_float(img_u16)
         out = torch.empty((F, Y, X), dtype=torch.float32, device=self.device)
         pct = torch.empty((F, 2), dtype=torch.float64, device=self.device)
         with self.eng.timed("normalize99"):
@@ -186,12 +195,32 @@ class CellposeModel:
                                                           _ptr(pct), _stream_ptr()))
         return out
 
-    def run_network(self, img_u16: torch.Tensor):
+    def _normalize_float(self, img: torch.Tensor) -> torch.Tensor:
+        """normalize99 for float images: exact order statistics by a device sort per image, numpy.percentile's linear
+        interpolation in float64, then the same (x - p1) / (p99 - p1) -> float32 rule as the uint16 kernel."""
+        F, Y, X = img.shape
+        flat = img.reshape(F, -1).to(torch.float64)
+        srt = torch.sort(flat, dim=1).values
+        n = srt.shape[1]
+        pct = []
+        for q in (1.0, 99.0):
+            pos = (n - 1) * (q / 100.0)
+            lo = int(np.floor(pos))
+            hi = min(lo + 1, n - 1)
+            a, b = srt[:, lo], srt[:, hi]
+            pct.append(a + (b - a) * (pos - lo))
+        x01, x99 = pct[0][:, None], pct[1][:, None]
+        out = torch.where(x99 - x01 > 1e-3, (flat - x01) / (x99 - x01), torch.zeros_like(flat))
+        return out.to(torch.float32).reshape(F, Y, X)
+
+    def run_network(self, img_u16: torch.Tensor, normalize: bool = True):
         """uint16 [F,Y,X] -> (dP float32 [F,2,Y,X], cellprob float32 [F,Y,X]) through the U-Net."""
         F, Y, X = img_u16.shape
         g = self._geometry(Y, X)
         lib, h = self.eng.lib, self.eng.ctx.handle
-        norm = self.normalize(img_u16)
+        # normalize=False: the raw values go to the network as float32, as cellpose does with its `normalize` switch off
+        norm = self.normalize(img_u16) if normalize else (
+            img_u16.to(torch.int32).to(torch.float32) if img_u16.dtype == torch.uint16 else img_u16.to(torch.float32)).contiguous()
         ntiles = F * g["ny"] * g["nx"]
         tiles = torch.empty((ntiles, 2, g["by"], g["bx"]), dtype=torch.float32, device=self.device)
         with self.eng.timed("make_tiles"):
@@ -223,15 +252,16 @@ class CellposeModel:
         if do_3D:
             raise NotImplementedError("do_3D is not wired by the reference pipeline (SURVEY §8d, C5 note)")
         if not isinstance(x, torch.Tensor):
-            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint16))
+            x = np.ascontiguousarray(x)
+            x = torch.from_numpy(x if x.dtype == np.uint16 else x.astype(np.uint16 if x.dtype in (np.uint8, np.bool_) else np.float32))
         x = x.to(self.device).contiguous()
         if x.ndim == 2:
             x = x[None]
-        if normalize is not True:
-            raise NotImplementedError("only normalize=True (the reference's call) is built")
+        if isinstance(normalize, dict):
+            raise NotImplementedError("normalize={...} (cellpose's per-option dict) is not built: True or False")
         dP = prob = None
         if self.flows_override is None or self.run_network_with_override:
-            dP, prob = self.run_network(x)
+            dP, prob = self.run_network(x, normalize=bool(normalize))
         if self.flows_override is not None:
             dP, prob = self.flows_override(x)
         labels, counts = dynamics.masks_from_flows(

@@ -42,35 +42,83 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
     device = setup_params.pop("device", None)
     model = CellposeModel(gpu=gpu, device=device, **setup_params)
 
-    def segment(pixels, do_3D: bool = False, stitch_threshold=None, **kw):
-        """Assumes FCZYX pixels.  Returns uint16 labels [Y,X] (monotile), as the reference does."""
-        dev_hit = devcache.lookup(pixels) if isinstance(pixels, np.ndarray) else None
-        z_size = pixels.shape[2]
-        if pixels.ndim > 5:
-            pixels = pixels[0]
-            dev_hit = None
-        if do_3D and z_size > 1:
-            raise NotImplementedError("3-D Cellpose (do_3D) is beyond what the pipeline wires (SURVEY §8d C5 note)")
-        src = dev_hit[0] if dev_hit is not None else pixels
-        plane = model.select_and_project(src, channel_to_segment)  # device [F,Y,X], max over Z if Z>1
-        result = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=True, z_axis=None, **kw)
-        labels_dev = result[0]  # device uint16 [F,Y,X] (or [Y,X] when F==1: "Cellpose squeezes dims")
+    def _device_block(pixels):
+        """host array / device tensor [F,C,Z,Y,X] of any real dtype -> device tensor the model takes (uint16 stays uint16,
+        uint8 / bool are widened losslessly, everything else becomes float32: dispatch.py:179-215 accepts any dtype)."""
+        import torch
+
+        hit = devcache.lookup(pixels) if isinstance(pixels, np.ndarray) else None
+        if hit is not None:
+            return hit[0]
+        if isinstance(pixels, torch.Tensor):
+            t = pixels.to(model.device)
+        else:
+            a = np.ascontiguousarray(pixels)
+            if a.dtype in (np.uint8, np.bool_):
+                a = a.astype(np.uint16)
+            elif a.dtype != np.uint16:
+                a = a.astype(np.float32)
+            t = torch.from_numpy(a).to(model.device)
+        if t.dtype == torch.uint8 or t.dtype == torch.bool:
+            t = t.to(torch.int32).to(torch.uint16)
+        elif t.dtype not in (torch.uint16, torch.float32):
+            t = t.to(torch.float32)
+        return t
+
+    def _labels_of(blocks, kw):
+        """One model.eval over every tile of every block: list of device blocks [F_i,C,Z,Y,X] -> labels [sum F_i,Y,X], counts."""
+        import torch
+
+        planes = [model.select_and_project(b, channel_to_segment) for b in blocks]  # [F_i,Y,X], max over Z if Z>1
+        plane = planes[0] if len(planes) == 1 else torch.cat(planes, 0)
+        result = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=kw.pop("normalize", True), z_axis=None, **kw)
+        labels = result[0]
+        return (labels if labels.ndim == 3 else labels[None]), np.asarray(model.last_counts)
+
+    def _finish(stack, counts):
+        """The reference's post-processing of one position's label stack [F,Y,X] (dispatch.py:216-234) -> step result."""
         if per_tile:
-            stack = labels_dev if labels_dev.ndim == 3 else labels_dev[None]
-            if max(model.last_counts, default=0) >= np.iinfo(np.uint16).max:
-                raise OverflowError(f"Segmentation produced {max(model.last_counts)} labels; uint16 cast unsafe.")
+            if counts.size and counts.max() >= np.iinfo(np.uint16).max:
+                raise OverflowError(f"Segmentation produced {counts.max()} labels; uint16 cast unsafe.")
             host = stack.cpu().numpy()
             return [devcache.attach(host[k], stack[k], kind="labels") for k in range(host.shape[0])]
-        if labels_dev.ndim == 3:
-            # reference: labels.max(axis=0) then relabel_sequential (dispatch.py:218-223)
-            labels_dev = model.max_project_and_relabel(labels_dev)
-        elif not 1 < labels_dev.ndim < 4:
-            raise Exception(f"Segmentation yielded {labels_dev.ndim} dimensions instead of 3")
-        n_labels = model.count_labels(labels_dev)
+        if stack.shape[0] > 1:
+            # reference: a 3-D result is collapsed, labels.max(axis=0) then relabel_sequential (dispatch.py:218-223)
+            labels_dev = model.max_project_and_relabel(stack)
+            n_labels = model.count_labels(labels_dev)
+        else:
+            labels_dev = stack[0]  # "Cellpose squeezes dims"
+            n_labels = int(counts[0]) if counts.size else 0
         if n_labels >= np.iinfo(np.uint16).max:
             raise OverflowError(f"Segmentation produced {n_labels} labels; uint16 cast unsafe.")
         host = labels_dev.cpu().numpy()
         return devcache.attach(host, labels_dev, kind="labels")
 
+    def segment(pixels, do_3D: bool = False, stitch_threshold=None, **kw):
+        """Assumes FCZYX pixels.  Returns uint16 labels [Y,X] (monotile), as the reference does."""
+        z_size = pixels.shape[2]
+        if pixels.ndim > 5:
+            pixels = pixels[0]
+        if do_3D and z_size > 1:
+            raise NotImplementedError("3-D Cellpose (do_3D) is beyond what the pipeline wires (SURVEY §8d C5 note)")
+        stack, counts = _labels_of([_device_block(pixels)], dict(kw))
+        return _finish(stack, counts)
+
+    def segment_batch(blocks, **kw):
+        """Position-batched form used by aliby_amd.runner: `blocks` = one FCZYX block per position (device tensors or host
+        arrays); every tile of every position goes through ONE network / dynamics pass, then each position's stack gets the
+        reference's post-processing on its own.  Returns one step result per position, identical to `segment(block)`."""
+        devs = [_device_block(b) for b in blocks]
+        stack, counts = _labels_of(devs, dict(kw))
+        out, k = [], 0
+        for d in devs:
+            f = d.shape[0]
+            out.append(_finish(stack[k : k + f], counts[k : k + f]))
+            k += f
+        return out
+
     segment.model = model
+    segment.batch = segment_batch
+    segment.channel_to_segment = channel_to_segment
+    segment.per_tile = per_tile
     return segment

@@ -87,6 +87,7 @@ class Tiler:
         self._dev_stack = {}  # tp -> device [C,Z,Y,X] (keeps the last two, like load_image's lru_cache(2))
         self._engine = None
         self._ingest_stream = self._ingest_pool = self._ingest_pending = None
+        self._crop_cache = None
         # The reference reads `calculate_drift` as an attribute a caller sets after construction (tiler.py:428-431); a
         # pipeline dict has no way to do that, so the step parameter of the same name is accepted here.
         if "calculate_drift" in kwargs:
@@ -111,6 +112,12 @@ class Tiler:
         logging.getLogger("aliby").debug(f"Tiler.run_tp took {(perf_counter() - t1):.4f}s")
         return out
 
+    def run_tp_device(self, tp: int):
+        """`run_tp` whose "pixels" stay on the device (a uint16 tensor [F,C,Z,h,w]) — what the position-batched runner
+        (aliby_amd/runner.py) hands to the segment / extract steps.  Tiles that the reference would return as float NaN
+        blocks (> 25 % outside the frame) have no device form: those timepoints come back through the host path."""
+        return self._run_tp(tp, device=True)
+
     def find_drift(self, tp: int):
         """Translational drift of frame `tp` against frame `tp - 1` on the reference channel / z plane
         (tiler.py:284-307): phase cross-correlation on the GPU (aliby_amd/tile/drift.py)."""
@@ -127,7 +134,7 @@ class Tiler:
         else:
             self.tile_locs.drifts.append(drift.tolist())
 
-    def _run_tp(self, tp: int):
+    def _run_tp(self, tp: int, device: bool = False):
         if self.no_processed == 0:
             if hasattr(self, "ref_channel_index"):
                 self.tile_locs = self._areas_of_interest()
@@ -148,6 +155,10 @@ class Tiler:
             else:
                 self.tile_locs.drifts.append(drift)
         self.no_processed = tp + 1
+        if device:
+            dev, flags = self.get_fczyx_device(tp)
+            if not flags.any():
+                return {"drift": self.tile_locs.to_dict(tp), "pixels": dev}
         return {"drift": self.tile_locs.to_dict(tp), "pixels": self.get_fczyx(tp)}
 
     def _areas_of_interest(self):
@@ -250,13 +261,22 @@ class Tiler:
 
         if self._engine is None:
             self._engine = FeatureEngine()
+        rects = self.rects(tp)
+        # the engine asks for the tiles of a timepoint once per consumer (its own step, then every segment step through
+        # passed_methods: pipe_core.py:211-215); the crop of a (tp, windows) pair is done once
+        key = (tp, rects.tobytes())
+        if self._crop_cache is not None and self._crop_cache[0] == key:
+            return self._crop_cache[1], self._crop_cache[2]
         stack = self._device_stack(tp)
         C, Z, Y, X = stack.shape
-        rects = self.rects(tp)
         F = len(rects)
         h, w = (int(rects[0, 2]), int(rects[0, 3])) if F else (0, 0)
-        out = torch.empty((F, C, Z, h, w), dtype=torch.uint16, device=stack.device)
         flags = np.zeros(max(F, 1), np.int32)
+        if F == 1 and tuple(rects[0]) == (0, 0, Y, X):
+            # monotile window = the whole frame: the stack itself is the tile block, no copy
+            self._crop_cache = (key, stack[None], flags[:F])
+            return stack[None], flags[:F]
+        out = torch.empty((F, C, Z, h, w), dtype=torch.uint16, device=stack.device)
         if F:
             _lib.check(
                 self._engine.lib.aliby_crop_pad_u16(
@@ -264,6 +284,7 @@ class Tiler:
                     _stream_ptr(),
                 )
             )
+        self._crop_cache = (key, out, flags[:F])
         return out, flags[:F]
 
     def get_fczyx(self, tp: int, drift: bool = True) -> np.ndarray:

@@ -47,8 +47,8 @@ class StitchTracker:
 
     @staticmethod
     def _dev(a):
-        d = devcache.lookup(a)
-        return d if d is not None else to_device_u16(np.asarray(a))
+        hit = devcache.lookup(a) if isinstance(a, np.ndarray) else None
+        return hit[0] if hit is not None else to_device_u16(np.asarray(a))
 
     def __call__(self, masks, track_info=None):
         """masks[k] = (older, newer) label images of tile k; track_info = the previous call's return value (or None /
@@ -64,10 +64,7 @@ class StitchTracker:
                 out[k] = {"labels": [int(r["label"]) if r["area"] > 0 else 0 for r in rows], "max_label": int(len(rows))}
             return out
         for pair in masks:
-            a, b = pair[0], pair[1]
-            da, db = devcache.lookup(a), devcache.lookup(b)
-            a = da if da is not None else to_device_u16(np.asarray(a))
-            b = db if db is not None else to_device_u16(np.asarray(b))
+            a, b = self._dev(pair[0]), self._dev(pair[1])
             if a.ndim != 2 or b.ndim != 2 or a.shape != b.shape:
                 raise AssertionError("Masks are in wrong dimensions")
             pairs.append((a, b))

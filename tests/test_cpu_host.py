@@ -363,3 +363,62 @@ def test_cpnet_checkpoint_layout_loads(tmp_path):
         unet.load_cellpose_state_dict(net, {**ckpt, "encoder.patch_embed.proj.weight": torch.zeros(1)})
     with pytest.raises(RuntimeError):  # another architecture: shapes are checked
         unet.load_cellpose_state_dict(net, {**ckpt, "output.2.weight": torch.zeros(5, 32, 1, 1)})
+
+
+_RUNNER_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, pyarrow.parquet, torch
+import torch.distributed as dist
+from aliby_amd import parallel
+from aliby_amd.parallel import run_positions
+
+rank, world, _ = parallel.init("gloo")
+out = os.environ["OUT"]
+
+class FakeTiler:  # steps without a device form: the runner walks them per position inside its batched loop
+    def __init__(self, k): self.k = k
+    def run_tp(self, tp): return {"drift": {}, "pixels": np.full((1, 1, 1, 4, 4), self.k, np.uint16)}
+
+def init(step_name, parameters, other=None):
+    if step_name == "tile":
+        return FakeTiler(parameters["k"])
+    if step_name == "nahual_embed_x":
+        return lambda pixels: np.arange(6, dtype=np.float64).reshape(2, 3) + float(pixels.flat[0])
+    raise ValueError(step_name)
+
+n = 5
+pipelines = [{"steps": {"tile": {"k": 10 * i}, "nahual_embed_x": {}}, "passed_data": {"nahual_embed_x": [("pixels", "tile")]}}
+             for i in range(n)]
+names = [f"pos{i}" for i in range(n)]
+got = run_positions(pipelines, names, out, init_step_fn=init, batch_size=2)
+mine = parallel.positions_for_rank(n, rank, world)
+assert [g[0] is not None for g in got] == [i in mine for i in range(n)]
+for i in mine:
+    t = pyarrow.parquet.read_table(os.path.join(out, "profiles", f"pos{i}.parquet"))
+    assert t.num_rows == 2 and t["X_0"].to_pylist() == [10.0 * i, 10.0 * i + 3]
+vals = torch.tensor(np.concatenate([got[i][0].select(["X_0", "X_1", "X_2"]).to_pandas().to_numpy() for i in mine]))
+meta = torch.tensor([[i, r, 0, 0] for i in mine for r in range(2)], dtype=torch.int64)
+v, m = parallel.gather_rows(vals, meta)
+parallel.barrier()
+if rank == 0:
+    assert sorted(os.listdir(os.path.join(out, "profiles"))) == [f"pos{i}.parquet" for i in range(n)]
+    assert v.shape == (2 * n, 3) and sorted(set(m[:, 0].tolist())) == list(range(n))
+    print("RUNNER_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_run_positions_shards_over_ranks_world_size_2_gloo(tmp_path):
+    """The N>1 path of the position runner on CPU: positions i % world == rank, each rank writes its own parquet files,
+    one gather of rows at the end; steps here are host-only stand-ins, so no GPU is needed."""
+    script = tmp_path / "worker.py"
+    script.write_text(_RUNNER_WORKER)
+    env = dict(os.environ, REPO=str(ROOT), MASTER_ADDR="127.0.0.1", OUT=str(tmp_path / "out"))
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29631", str(script)],
+        env=env, capture_output=True, text=True, timeout=240,
+    )
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "RUNNER_OK" in out.stdout

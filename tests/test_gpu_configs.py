@@ -62,13 +62,18 @@ def test_config2_full_default_tree_1024_5ch(tmp_path, engine):
     got = profiles.to_pandas()
     assert got["metadata_label"].tolist() == list(range(1, n + 1))  # first-seen (tile, label) row order
     assert (got["metadata_tile"] == 0).all() and (got["metadata_object"] == "nuclei").all() and (got["metadata_tp"] == 0).all()
-    assert pyarrow.parquet.read_table(tmp_path / "profiles" / "C2__0.parquet").equals(profiles)
+    on_disk = pyarrow.parquet.read_table(tmp_path / "profiles" / "C2__0.parquet")
+    assert on_disk.schema.equals(profiles.schema)
+    assert all(np.array_equal(on_disk[c].to_numpy(), profiles[c].to_numpy(), equal_nan=True) for c in profiles.column_names
+               if c != "metadata_object")
 
     # ---- every object: size-independent properties
     area = np.bincount(want_mask.ravel())[1:]
     assert np.array_equal(got["None/None/sizeshape/Area"].to_numpy(), area.astype(float))
-    values = got.drop(columns=["metadata_object"]).to_numpy(float)
-    assert np.isfinite(values).mean() > 0.999  # NaN only where a definition is undefined (e.g. a texture direction with no pairs)
+    values = got.drop(columns=["metadata_object"])
+    nan_cols = sorted(c for c in values.columns if not np.isfinite(values[c].to_numpy(float)).all())
+    # NaN only where the definition is: scikit-image's normalised moments of order < 2
+    assert nan_cols == [f"None/None/sizeshape/NormalizedMoment_{i}_{j}" for i, j in ((0, 0), (0, 1), (1, 0))], nan_cols
     for c in range(5):
         px = f["pixels"][c, 0].astype(np.float64)
         tot = np.bincount(want_mask.ravel(), weights=px.ravel())[1:]
@@ -290,3 +295,68 @@ def test_coloc_kwargs_are_per_metric(engine):
     b = process_tree_masks(tree, labels, pixels, extract_tree_multi, cp_measure_kwargs={})[1]
     assert any(not np.allclose(x["Correlation_Manders_1"], y["Correlation_Manders_1"]) for x, y in zip(a, b) if "Correlation_Manders_1" in x)
     assert all(np.allclose(x["Correlation_RWC_1"], y["Correlation_RWC_1"]) for x, y in zip(a, b) if "Correlation_RWC_1" in x)
+
+
+# --------------------------------------------------------------------------------- the position-batched runner
+def _keyed_override(fovs, key_channel=0):
+    """flows_override for a batch: each plane of x [N,Y,X] is looked up by its bytes, so the same closure serves single calls
+    (N = 1) and batched calls (N = positions) in any order."""
+    import torch
+
+    table = {}
+    for f in fovs:
+        dP, prob = synth.analytic_flows(f["nuclei"])
+        table[f["pixels"][key_channel].max(axis=0).tobytes()] = (dP, prob)
+
+    def override(x):
+        host = x.cpu().numpy()
+        flows = [table[host[i].tobytes()] for i in range(host.shape[0])]
+        return (torch.from_numpy(np.stack([fl[0] for fl in flows])).cuda(), torch.from_numpy(np.stack([fl[1] for fl in flows])).cuda())
+
+    return override
+
+
+def test_run_positions_writes_what_single_calls_write(tmp_path, engine):
+    """aliby_amd.runner.run_positions (B positions per device step) against N calls of run_pipeline_and_post: the same
+    parquet bytes, the same mask arrays, the same returned tables; resume-by-skip per position (pipe_core.py:408,446-448)."""
+    import pyarrow.parquet
+
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    n = 7
+    fovs = [synth.make_fov(2, 40 + i, shape=(224, 256), n_channels=3, n_target=10 + i) for i in range(n)]
+    override = _keyed_override(fovs)
+
+    def pipelines():
+        out = []
+        for f in fovs:
+            p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1, 2],
+                                     cp_measure_feature_kwargs={"texture": {"scale": 2}})
+            p["steps"]["tile"]["image_kwargs"] = {"source": f["pixels"][None]}
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+            out.append(p)
+        return out
+
+    names = [f"P{i:02d}__1" for i in range(n)]
+    single, batched = tmp_path / "single", tmp_path / "batched"
+    want = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=single)[0] for p, nm in zip(pipelines(), names)]
+    got = run_positions(pipelines(), names, batched, batch_size=3)  # batches of 3, 3, 1
+    assert len(got) == n
+    for i, nm in enumerate(names):
+        prof, post = got[i]
+        assert post == {} and prof.schema.equals(want[i].schema) and prof.num_rows == want[i].num_rows > 0
+        for c in prof.column_names:
+            a, b = prof[c].to_numpy(zero_copy_only=False), want[i][c].to_numpy(zero_copy_only=False)
+            assert np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")), (nm, c)
+        assert (batched / "profiles" / f"{nm}.parquet").read_bytes() == (single / "profiles" / f"{nm}.parquet").read_bytes()
+        with np.load(batched / "steps" / nm / "segment_nuclei" / "0000.npz") as za, \
+                np.load(single / "steps" / nm / "segment_nuclei" / "0000.npz") as zb:
+            assert list(za.keys()) == list(zb.keys()) == ["arr_0"] and np.array_equal(za["arr_0"], zb["arr_0"])
+    # resume: nothing to do -> (None, None) everywhere; after deleting one file only that position is redone
+    assert run_positions(pipelines(), names, batched, overwrite=False) == [(None, None)] * n
+    (batched / "profiles" / f"{names[4]}.parquet").unlink()
+    again = run_positions(pipelines(), names, batched, overwrite=False)
+    assert [a[0] is not None for a in again] == [i == 4 for i in range(n)]
+    assert (batched / "profiles" / f"{names[4]}.parquet").read_bytes() == (single / "profiles" / f"{names[4]}.parquet").read_bytes()
