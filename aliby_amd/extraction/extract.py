@@ -231,29 +231,56 @@ def process_tree_masks_overlap(*args, **kwargs):
 # --------------------------------------------------------------------------------------------
 
 
+_LAYOUTS: dict = {}
+
+
+def _dense_layout(results: DeviceResults):
+    """(sorted metric names, matrix column of each) for a results layout; the same for every position of a run, so it is
+    worked out once.  Duplicate metric names collapse to the last writer, as the reference's dict pivot does."""
+    key = (tuple(results.instructions), tuple((s, None if k is None else len(k)) for s, k in results.blocks))
+    hit = _LAYOUTS.get(key)
+    if hit is None:
+        names = results.column_names()
+        flat_cols = []
+        for inst, (start, keys) in zip(results.instructions, results.blocks):
+            flat_cols.extend(range(start, start + (1 if keys is None else len(keys))))
+        last = {}
+        for j in sorted(range(len(names)), key=names.__getitem__):
+            last[names[j]] = flat_cols[j]
+        ordered = sorted(last)
+        fields = [pa.field("tile", pa.int64()), pa.field("label", pa.int64())] + [pa.field(n, pa.float64()) for n in ordered]
+        hit = _LAYOUTS[key] = (pa.schema(fields), np.asarray([last[n] for n in ordered], dtype=np.intp))
+        if len(_LAYOUTS) > 64:
+            _LAYOUTS.pop(next(iter(_LAYOUTS)))
+    return hit
+
+
 def _format_dense(instructions, results: DeviceResults) -> pa.Table:
     """Columnar equivalent of the reference pivot for a full objects x instructions product:
-    rows in first-seen (tile, label) order, metric columns sorted (extract.py:574-596)."""
-    names = results.column_names()
-    order = sorted(range(len(names)), key=names.__getitem__)
-    # duplicate metric names collapse to the last writer, as the dict pivot does
-    last = {}
-    for j in order:
-        last[names[j]] = j
-    cols = {"tile": pa.array([t for t, _ in results.objects], pa.int64()),
-            "label": pa.array([l for _, l in results.objects], pa.int64())}
-    flat_cols = []
-    for inst, (start, keys) in zip(results.instructions, results.blocks):
-        flat_cols.extend(range(start, start + (1 if keys is None else len(keys))))
-    for name in sorted(last):
-        cols[name] = pa.array(np.ascontiguousarray(results.matrix[:, flat_cols[last[name]]]), pa.float64())
-    return pa.table(cols)
+    rows in first-seen (tile, label) order, metric columns sorted (extract.py:574-596).  One transposed copy of the feature
+    matrix, then every Arrow column is a window of that buffer (no per-value Python work)."""
+    schema, take = _dense_layout(results)
+    matrix = results.matrix
+    n = matrix.shape[0]
+    block = np.ascontiguousarray(matrix[:, take].T)  # [n_cols, n_rows], C order: row j = column j of the table
+    buf = pa.py_buffer(block)
+    f64 = pa.float64()
+    objs = np.asarray(results.objects, dtype=np.int64).reshape(n, 2)
+    arrays = [pa.array(np.ascontiguousarray(objs[:, 0])), pa.array(np.ascontiguousarray(objs[:, 1]))]
+    step = n * 8
+    arrays.extend(pa.Array.from_buffers(f64, n, [None, buf.slice(j * step, step)]) for j in range(block.shape[0]))
+    return pa.Table.from_arrays(arrays, schema=schema)
+
+
+_Dense = object()  # marker: "the instructions are the full product of results.objects x results.instructions"
 
 
 def format_extraction(instructions_result) -> pa.Table:
     """(instructions, results) -> wide pyarrow table (extract.py:520-599)."""
     if isinstance(instructions_result, (tuple, list)) and len(instructions_result) == 2:
         inst, res = instructions_result
+        if inst is _Dense and isinstance(res, DeviceResults) and res._pairs is None:
+            return _format_dense(None, res) if len(res) else pa.table({"tile": pa.array([], pa.int64()), "label": pa.array([], pa.int64())})
         if isinstance(res, DeviceResults) and res._pairs is None and isinstance(inst, PRODUCT_TYPES):
             if len(inst) != len(res):
                 raise ValueError("zip() argument 2 is shorter than argument 1" if len(res) < len(inst)

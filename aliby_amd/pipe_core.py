@@ -314,8 +314,29 @@ def get_profiles_from_state(state: dict, pipeline: dict) -> pa.Table:
         return _empty_profiles()
     profiles = merged[0]
     for other in merged[1:]:
-        profiles = profiles.join(other, keys=[f"metadata_{k}" for k in _META_KEYS])
+        profiles = _join_on_metadata(profiles, other)
     return profiles
+
+
+def _join_on_metadata(left: pa.Table, right: pa.Table, strict: bool = False) -> pa.Table:
+    """`left.join(right, keys=metadata_*)` (pipe_core.py:499-510; pyarrow's default left outer join).  Both sides come from
+    the same object table, so their key columns are normally equal row for row: the join is then the left table plus the
+    right table's other columns, without building an Acero plan for a thousand-column table (tens of ms per position).
+    Anything else goes through pyarrow's join."""
+    keys = [f"metadata_{k}" for k in _META_KEYS]
+    if left.num_rows == right.num_rows and all(k in left.column_names and k in right.column_names for k in keys) and all(
+            left[k].equals(right[k]) for k in keys) and not (set(left.column_names) & set(right.column_names)) - set(keys):
+        out = left
+        names = list(left.column_names)
+        arrays = list(left.columns)
+        for name in right.column_names:
+            if name not in keys:
+                names.append(name)
+                arrays.append(right[name])
+        return pa.Table.from_arrays(arrays, names=names)
+    if strict:  # the caller relies on the row order of the left table: no plan-ordered join
+        return None
+    return left.join(right, keys=keys)
 
 
 # ------------------------------------------------------------------------------------------------

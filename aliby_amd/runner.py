@@ -24,6 +24,7 @@ collective, the optional end-of-run gather of rows is `parallel.gather_rows`.
 
 from __future__ import annotations
 
+import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
 from itertools import product
@@ -112,13 +113,86 @@ class _Product:
 ex.PRODUCT_TYPES = (tuple, list, _Product)
 
 
+class _Phase:
+    """with-block that adds its wall time (device drained on both sides) to measure[phase]; a no-op when not measuring."""
+
+    def __init__(self, store, phase):
+        self.store, self.phase = store, phase
+
+    def __enter__(self):
+        if self.store is not None:
+            import time
+
+            _sync()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.store is not None:
+            import time
+
+            _sync()
+            self.store[self.phase] = self.store.get(self.phase, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
+def _sync():
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except ImportError:
+        pass
+
+
+class _WriterProcess:
+    """One `python -m aliby_amd.io.writer_proc` child, owned by one writer thread (see that module for the why)."""
+
+    def __init__(self):
+        import subprocess
+        import sys
+
+        root = str(Path(__file__).resolve().parents[1])
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+        self.proc = subprocess.Popen([sys.executable, "-m", "aliby_amd.io.writer_proc"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                     text=True, bufsize=1, env=env)
+
+    def write(self, ipc, parts, out):
+        import json
+
+        self.proc.stdin.write(json.dumps({"ipc": ipc, "parts": parts, "out": str(out)}) + "\n")
+        self.proc.stdin.flush()
+        reply = self.proc.stdout.readline()
+        if not reply:
+            raise RuntimeError(f"parquet writer process died (exit code {self.proc.poll()})")
+        reply = json.loads(reply)
+        if not reply.get("ok"):
+            raise RuntimeError(f"parquet writer process: {reply.get('error')}")
+
+    def close(self):
+        try:
+            self.proc.stdin.close()
+            self.proc.wait(timeout=10)
+        except Exception:
+            self.proc.kill()
+
+
 class BatchRunner:
-    def __init__(self, init_step_fn, writers: int = 8):
+    def __init__(self, init_step_fn, writers: int = 8, measure: bool = False, writer_processes: bool = False):
         self.shared = _SharedSteps(init_step_fn)
         self.pool = ThreadPoolExecutor(max_workers=max(1, writers), thread_name_prefix="aliby-writer")
+        self.writer_processes = writer_processes and os.access("/dev/shm", os.W_OK)
+        self._procs, self._procs_lock, self._local = [], threading.Lock(), threading.local()
+        self._ipc_files, self._ipc_seq = {}, 0
         self.ingest = ThreadPoolExecutor(max_workers=1, thread_name_prefix="aliby-ingest")
-        self.timing = {}
+        self.measure = {} if measure else None  # phase -> seconds, every phase synchronised (diagnostic mode)
         self._tables = {}
+        self._dense = {}  # extract step -> whole-batch results of the batch in flight
+        self._h2d_stream = None
+
+    def _timed(self, phase):
+        return _Phase(self.measure, phase)
 
     # ------------------------------------------------------------------------------------------------ tile step
     def _tile_batch(self, batch, name, tp):
@@ -205,14 +279,19 @@ class BatchRunner:
         table = hit[0]
         matrix, blocks = families.evaluate(eng, lab_all, table, (px_all, pixels[0][1]), instructions, cp_kwargs, multi=multi)
         download = eng.to_host_async((matrix,), slot=None)
-        out, t0 = [], 0
+        out, t0, bounds, every = [], 0, [], []
         for pos, nt in zip(batch, tiles_of):
             lo, hi = int(table.offsets[t0]), int(table.offsets[t0 + nt])
             rows = table.host[lo:hi]
             objects = [(int(t) - t0, int(l)) for t, l in zip(rows["tile"], rows["label"])]
             res = ex.DeviceResults(_LazyRows(download, 0, lo, hi), objects, instructions, blocks)
             out.append((_Product(objects, instructions), res))
+            bounds.append((lo, hi))
+            every.extend(objects)
             t0 += nt
+        if tp == 0:  # what _profiles_for_batch needs to pivot the whole batch at once
+            self._dense[name] = dict(results=ex.DeviceResults(_LazyRows(download, 0, 0, len(every)), every, instructions, blocks),
+                                     bounds=bounds)
         return out
 
     # --------------------------------------------------------------------------------------------------- the loop
@@ -220,36 +299,60 @@ class BatchRunner:
         wanted = pos.pipeline.get("save") or []
         every = pos.pipeline.get("save_interval", 1)
         if wanted and every > 0 and tp % every == 0 and step_name in wanted:
+            if self.measure is not None:
+                with self._timed("write: step outputs (.npz, zlib)"):
+                    dispatch_write_fn(step_name)(result, steps_dir=pos.steps_dir, subpath=step_name, tp=tp)
+                return
             pos.pending.append(self.pool.submit(dispatch_write_fn(step_name), result, steps_dir=pos.steps_dir, subpath=step_name, tp=tp))
 
-    def run_batch(self, batch):
-        """All timepoints of a batch of positions with one signature.  Returns one future per position -> (profiles, {})."""
+    def prepare(self, batch):
+        """States of a batch and the first timepoint of its leading tile step, on the caller's thread: run_positions calls this
+        for batch k+1 on the ingest thread while batch k computes; uploads go to a side stream, `ready` marks their end."""
         steps = batch[0].pipeline["steps"]
-        ntps = batch[0].pipeline.get("ntps", 1)
         for pos in batch:
             pos.engine = pipe_core.Engine(pos.pipeline, pos.steps_dir, self.shared.get)
             pos.state = pos.engine.fresh_state(steps)
+        first = next(iter(steps))
+        batch[0].prefetched = None
+        if not first.startswith("tile"):
+            return
+        try:
+            import torch
+
+            cuda = torch.cuda.is_available()
+        except ImportError:
+            cuda = False
+        if not cuda:
+            batch[0].prefetched = (first, self._tile_batch(batch, first, 0), None)
+            return
+        if self._h2d_stream is None:
+            self._h2d_stream = torch.cuda.Stream()
+        with self._timed("tile: ingest + H2D"):
+            with torch.cuda.stream(self._h2d_stream):
+                results = self._tile_batch(batch, first, 0)
+                ready = torch.cuda.Event()
+                ready.record(self._h2d_stream)
+        batch[0].prefetched = (first, results, ready)
+
+    def run_batch(self, batch):
+        """All timepoints of a batch of positions with one signature.  Returns one future per position -> (profiles, {})."""
+        import contextlib
+
+        steps = batch[0].pipeline["steps"]
+        ntps = batch[0].pipeline.get("ntps", 1)
+        if batch[0].state is None:
+            self.prepare(batch)
+        pre, batch[0].prefetched = getattr(batch[0], "prefetched", None), None
+        self._dense = {}
         for tp in range(ntps):
             self._tables = {}
             for name in steps:
                 results = None
-                if len(batch) > 0:
-                    if name.startswith("tile"):
-                        results = self._tile_batch(batch, name, tp)
-                    elif name.startswith("segment"):
-                        results = self._segment_batch(batch, name, tp)
-                    elif name.startswith("extract_"):
-                        results = self._extract_batch(batch, name, tp, multi=False)
-                    elif name.startswith("extractmulti_"):
-                        results = self._extract_batch(batch, name, tp, multi=True)
-                if results is None:  # no batched form (or not applicable): the engine's own per-position path for this step
-                    results = []
-                    for pos in batch:
-                        pos.state["data"].setdefault(name, [])
-                        if name not in pos.state["fn"]:
-                            pos.state["fn"][name] = self.shared.get(name, pos.pipeline["steps"][name], pos.state["fn"])
-                        results.append(pipe_core.run_step(pos.state["fn"][name], *pos.engine._method_args(name, pos.state, tp), tp=tp,
-                                                          **pos.engine._inputs_for(name, pos.state)))
+                phase = ("tile: ingest + H2D" if name.startswith("tile") else "segment: project + normalise + network + dynamics + labels D2H"
+                         if name.startswith("segment") else "extract: object table + feature kernels + rows D2H"
+                         if name.startswith("extract") else f"step {name}")
+                with self._timed(phase) if not (tp == 0 and pre is not None and pre[0] == name) else contextlib.nullcontext():
+                    results = self._run_step_batched(batch, name, tp, pre)
                 for pos, result in zip(batch, results):
                     pos.state["data"].setdefault(name, [])
                     self._save(pos, name, result, tp)
@@ -257,12 +360,137 @@ class BatchRunner:
                     pos.state["tps"][name] = tp + 1
             for pos in batch:
                 pos.engine._end_of_timepoint(pos.state)
-        return [self.pool.submit(self._finish, pos) for pos in batch]
+        dense, self._dense = self._dense, {}
+        names = [n for n in steps if n.startswith("extract") or n.startswith("nahual_embed")]
+        whole = None
+        if ntps == 1 and names and all(n in dense for n in names):
+            whole = _Once(lambda: self._profiles_for_batch(batch, names, dense))  # one pivot + join for the batch, on a writer thread
+        if self.measure is not None:
+            return [_Done(self._finish(pos, whole, k)) for k, pos in enumerate(batch)]
+        return [self.pool.submit(self._finish, pos, whole, k) for k, pos in enumerate(batch)]
 
-    def _finish(self, pos):
-        profiles = pipe_core.get_profiles_from_state(pos.state, pos.pipeline)
-        pos.profiles_file.parent.mkdir(parents=True, exist_ok=True)
-        pyarrow.parquet.write_table(profiles, pos.profiles_file, compression="zstd")
+    def _profiles_for_batch(self, batch, names, dense):
+        """get_profiles_from_state (pipe_core.py:453-512) for every position of a one-timepoint batch at once: each extract
+        step's rows are pivoted ONCE for the batch (they sit in one matrix), the step prefixes are joined ONCE, and a position's
+        table is a zero-copy slice — the per-column Python work of a thousand-column table is paid per batch, not per position.
+        Returns None when the batch does not have the shape this relies on (the per-position path then does the work)."""
+        with self._timed("profiles: rows -> Arrow table, join"):
+            by_prefix = {}
+            for n in names:
+                by_prefix.setdefault(n.split("_")[0], []).append(n)
+            groups = list(by_prefix.values())
+            if len({len(g) for g in groups}) != 1:
+                return None
+            wide = {n: pipe_core._wide_table(n, 0, (ex._Dense, dense[n]["results"])) for n in names}
+            joined = []
+            for i in range(len(groups[0])):
+                members = [g[i] for g in groups]
+                if any(dense[m]["bounds"] != dense[members[0]]["bounds"] for m in members) or any(wide[m] is None for m in members):
+                    return None
+                table = wide[members[0]]
+                for m in members[1:]:
+                    table = pipe_core._join_on_metadata(table, wide[m], strict=True)
+                    if table is None:
+                        return None
+                joined.append((table, dense[members[0]]["bounds"]))
+            ipc = self._export_ipc(joined, len(batch)) if self.writer_processes else None
+            return joined, ipc
+
+    def _export_ipc(self, joined, n_positions):
+        """The batch's tables as ONE Arrow IPC stream in /dev/shm for the writer processes; -> (path, row offset of each table)."""
+        import pyarrow as pa
+
+        schema = joined[0][0].schema
+        if any(not t.schema.equals(schema) for t, _ in joined[1:]):
+            return None
+        with self._procs_lock:
+            self._ipc_seq += 1
+            path = f"/dev/shm/aliby_{os.getpid()}_{id(self) & 0xffffff:x}_{self._ipc_seq}.arrow"
+            self._ipc_files[path] = n_positions  # positions still to be written from this file
+        offsets, row = [], 0
+        with pa.OSFile(path, "wb") as sink, pa.ipc.new_stream(sink, schema) as writer:
+            for t, _ in joined:
+                offsets.append(row)
+                writer.write_table(t)
+                row += t.num_rows
+        return path, offsets
+
+    def _release_ipc(self, path):
+        with self._procs_lock:
+            left = self._ipc_files.get(path, 0) - 1
+            if left > 0:
+                self._ipc_files[path] = left
+                return
+            self._ipc_files.pop(path, None)
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+    def _my_process(self):
+        proc = getattr(self._local, "proc", None)
+        if proc is None:
+            proc = self._local.proc = _WriterProcess()
+            with self._procs_lock:
+                self._procs.append(proc)
+        return proc
+
+    def _run_step_batched(self, batch, name, tp, pre):
+        results = None
+        if tp == 0 and pre is not None and pre[0] == name:
+            import torch
+
+            if pre[2] is not None:
+                torch.cuda.current_stream().wait_event(pre[2])  # the uploads of the ingest thread
+                main = torch.cuda.current_stream()
+                for r in pre[1]:
+                    px = r.get("pixels") if isinstance(r, dict) else None
+                    if isinstance(px, torch.Tensor):
+                        px.record_stream(main)
+            return pre[1]
+        if name.startswith("tile"):
+            results = self._tile_batch(batch, name, tp)
+        elif name.startswith("segment"):
+            results = self._segment_batch(batch, name, tp)
+        elif name.startswith("extract_"):
+            results = self._extract_batch(batch, name, tp, multi=False)
+        elif name.startswith("extractmulti_"):
+            results = self._extract_batch(batch, name, tp, multi=True)
+        if results is None:  # no batched form (or not applicable): the engine's own per-position path for this step
+            results = []
+            for pos in batch:
+                pos.state["data"].setdefault(name, [])
+                if name not in pos.state["fn"]:
+                    pos.state["fn"][name] = self.shared.get(name, pos.pipeline["steps"][name], pos.state["fn"])
+                results.append(pipe_core.run_step(pos.state["fn"][name], *pos.engine._method_args(name, pos.state, tp), tp=tp,
+                                                  **pos.engine._inputs_for(name, pos.state)))
+        return results
+
+    def _finish(self, pos, whole=None, k=0):
+        got = whole.get() if whole is not None else None
+        joined, ipc = got if got is not None else (None, None)
+        written = False
+        if joined is not None:
+            import pyarrow as pa
+
+            parts = [t.slice(b[k][0], b[k][1] - b[k][0]) for t, b in joined if b[k][1] > b[k][0]]
+            profiles = pa.concat_tables(parts) if parts else pipe_core._empty_profiles()
+            if ipc is not None:
+                try:
+                    if parts:
+                        rows = [[off + b[k][0], b[k][1] - b[k][0]] for (t, b), off in zip(joined, ipc[1]) if b[k][1] > b[k][0]]
+                        with self._timed("write: parquet (zstd)"):
+                            self._my_process().write(ipc[0], rows, pos.profiles_file)
+                        written = True
+                finally:
+                    self._release_ipc(ipc[0])
+        else:
+            with self._timed("profiles: rows -> Arrow table, join"):
+                profiles = pipe_core.get_profiles_from_state(pos.state, pos.pipeline)
+        if not written:
+            with self._timed("write: parquet (zstd)"):
+                pos.profiles_file.parent.mkdir(parents=True, exist_ok=True)
+                pyarrow.parquet.write_table(profiles, pos.profiles_file, compression="zstd")
         for f in pos.pending:
             f.result()
         pos.state = pos.engine = None  # releases the device blocks of this position
@@ -271,6 +499,34 @@ class BatchRunner:
     def close(self):
         self.pool.shutdown(wait=True)
         self.ingest.shutdown(wait=True)
+        for proc in self._procs:
+            proc.close()
+        for path in list(self._ipc_files):  # only after an error: every file is normally released by its last position
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+
+class _Once:
+    """A value computed by whichever thread asks first; the others wait for it."""
+
+    def __init__(self, fn):
+        self.fn, self.lock, self.done, self.value = fn, threading.Lock(), False, None
+
+    def get(self):
+        with self.lock:
+            if not self.done:
+                self.value, self.done, self.fn = self.fn(), True, None
+            return self.value
+
+
+class _Done:
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
 
 
 def _cat(tensors):
@@ -294,12 +550,14 @@ def _cat(tensors):
 
 
 def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_size: int = 16, init_step_fn=None,
-                  writers: int = 8, shard: bool = True):
+                  writers: int | None = None, shard: bool = True, measure: bool = False, stats: dict | None = None,
+                  writer_processes: bool | None = None):
     """`run_pipeline_and_post` for many positions: pipelines[i] / names[i] -> profiles/<names[i]>.parquet (+ step outputs).
 
     Returns a list aligned with `pipelines`: (pyarrow.Table, {}) for the positions this rank processed, (None, None) for
     positions skipped by resume (`overwrite=False` and the parquet exists) or owned by another rank (`shard=True` under
-    torch.distributed.run: positions i % world == rank, examples/01:100-104's round-robin)."""
+    torch.distributed.run: positions i % world == rank, examples/01:100-104's round-robin).
+    measure=True (diagnostic): every phase runs synchronised and inline, and the return value is {phase: ms per position}."""
     from aliby_amd import parallel
 
     if init_step_fn is None:
@@ -317,19 +575,62 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
             pipe_core.logger.info(f"Skipping {names[i]}")
             continue
         todo.append(pos)
-    runner = BatchRunner(init_step_fn, writers=writers)
+    batches, k = [], 0
+    while k < len(todo):
+        sig = _signature(todo[k].pipeline)
+        batch = [todo[k]]
+        while len(batch) < batch_size and k + len(batch) < len(todo) and _signature(todo[k + len(batch)].pipeline) == sig:
+            batch.append(todo[k + len(batch)])
+        batches.append(batch)
+        k += len(batch)
+    if writers is None:
+        from aliby_amd import hostinfo
+
+        writers = max(2, hostinfo.usable_cores() - 4)  # leave the launch thread, the ingest thread and the runtime's own threads room
+        # inside the CPU quota: when every core of the share is busy writing, the launch thread is throttled with them
+    if writer_processes is None:  # worth their start-up (an interpreter + pyarrow import each) from a few batches on
+        writer_processes = len(todo) >= 4 * batch_size and not measure
+    runner = BatchRunner(init_step_fn, writers=writers, measure=measure, writer_processes=writer_processes)
     futures = []
     try:
-        k = 0
-        while k < len(todo):
-            sig = _signature(todo[k].pipeline)
-            batch = [todo[k]]
-            while len(batch) < batch_size and k + len(batch) < len(todo) and _signature(todo[k + len(batch)].pipeline) == sig:
-                batch.append(todo[k + len(batch)])
+        device = None
+        try:
+            import torch
+
+            device = torch.cuda.current_device() if torch.cuda.is_available() else None
+        except ImportError:
+            pass
+
+        def prepare(batch):
+            if device is not None:
+                torch.cuda.set_device(device)  # (the current device is per thread)
+            runner.prepare(batch)
+
+        import time
+
+        nxt = None
+        clock = {"wait_ingest_s": 0.0, "device_steps_s": 0.0, "drain_writers_s": 0.0}
+        for b, batch in enumerate(batches):
+            t0 = time.perf_counter()
+            if measure:
+                runner.prepare(batch)
+            else:
+                (nxt or runner.ingest.submit(prepare, batch)).result()
+                nxt = runner.ingest.submit(prepare, batches[b + 1]) if b + 1 < len(batches) else None
+            t1 = time.perf_counter()
             futures.extend(zip(batch, runner.run_batch(batch)))
-            k += len(batch)
+            t2 = time.perf_counter()
+            clock["wait_ingest_s"] += t1 - t0
+            clock["device_steps_s"] += t2 - t1
+        t0 = time.perf_counter()
         for pos, fut in futures:
             out[pos.index] = fut.result()
+        clock["drain_writers_s"] = time.perf_counter() - t0
+        if stats is not None:
+            stats.update({k: round(v, 4) for k, v in clock.items()}, batches=len(batches), writers=writers)
     finally:
         runner.close()
+    if measure:
+        n = max(len(todo), 1)
+        return {phase: round(1e3 * sec / n, 4) for phase, sec in runner.measure.items()}
     return out

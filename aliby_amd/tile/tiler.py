@@ -212,7 +212,10 @@ class Tiler:
             raise NotImplementedError(
                 f"stager handles uint16 stacks (the reference's fixtures, SURVEY §3.3); got {block.dtype}"
             )
-        return torch.from_numpy(block).cuda()
+        src = torch.from_numpy(block)
+        # page-locked host memory goes up asynchronously on the current stream at PCIe rate (pageable memory is staged by the
+        # runtime at a quarter of it); torch's host allocator keeps a pinned block alive until the copy has run
+        return src.cuda(non_blocking=src.is_pinned())
 
     def _ingest(self, tp: int):
         """File-backed stacks (aliby_amd/io/image.py): decode + upload through csrc/ingest.hip on a side stream, and

@@ -7,6 +7,7 @@ torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
 Workload = config 2 of BASELINE.json (the configuration the metric is quoted on): 1024x1024, 5-channel
 Cell Painting synthetic FOVs (~250 nuclei each), Cellpose nuclei segmentation on the DNA channel + the
 full default cp_measure feature list + sizeshape + 10 channel pairs x 4 colocalisation metrics.
+`--config {1,2,4,5}` selects another BASELINE configuration (2 is the default and the one the metric is quoted on).
 A "step" is one pass of the hot path over one batch of B FOVs per GPU, inputs resident in HBM:
 
     stage (crop/pad)                                                   HIP
@@ -20,7 +21,13 @@ Cellpose's pretrained weights cannot be fetched offline: 
 fixed-seed random weights (its full cost is paid inside the timed region, its output is discarded) and
 the dynamics are fed analytic network-scale flows derived from the synthetic ground truth, so masks and
 feature workloads are realistic and checkable.  FOVs are independent: ranks shard them with no
-data-path collective ("scaling": "weak"); the only exchange is the final gather of profile rows.
+data-path collective ("scaling": "weak"; `--total-fovs N` fixes the job instead: N FOVs split over the ranks,
+"scaling": "strong"); the only exchange is the final gather of profile rows.
+
+Besides `value` (the HBM-resident rate the contract asks for) the line carries `value_api`: the same workload THROUGH the
+step API — pinned host arrays -> build_pipeline_steps() dicts -> aliby_amd.parallel.run_positions (Tiler -> segment -> extract ->
+get_profiles_from_state -> parquet + mask .npz on disk), B positions per device step — and `api_split_ms_per_fov`, where that
+time goes (H2D, kernels, table assembly, file writes), from a synchronised pass of the same runner.
 """
 
 from __future__ import annotations
@@ -41,16 +48,17 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def build_trees(channels):
-    """The builder's trees (pipe_builder.py:108-129) for one object set segmented on channel 0."""
+def build_trees(channels, seg_channel=0, features=None):
+    """The builder's trees (pipe_builder.py:108-129) for one object set."""
     from aliby_amd.extraction import families
     from aliby_amd.extraction.engine import FeatureEngine
     from aliby_amd.pipe_builder import build_pipeline_steps
 
     families.register_optional(FeatureEngine)
-    pipe = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=list(channels))
+    kw = {} if features is None else {"features_to_extract": tuple(features)}
+    pipe = build_pipeline_steps(channels_to_segment={"nuclei": seg_channel}, channels_to_extract=list(channels), **kw)
     mono = pipe["steps"]["extract_nuclei"]["tree"]
-    multi = pipe["steps"]["extractmulti_nuclei"]["tree"]
+    multi = pipe["steps"].get("extractmulti_nuclei", {}).get("tree", {})
     missing = sorted({m for v in mono.values() for vv in v.values() for m in vv if m not in families.MONO}
                      | {m for v in multi.values() for vv in v.values() for vvv in vv.values() for m in vvv
                         if m not in families.MULTI})
@@ -64,6 +72,7 @@ def alg_bytes(kernel, B, C, Z, Y, X, n_obj, n_tiles_net):
     P = Y * X
     table = {
         "stage_crop_pad": 2 * B * C * Z * P * 2,
+        "reduce_z": B * C * (Z + 1) * P * 2,
         "select_project": B * Z * P * 2 + B * P * 2,
         "normalize99": B * P * 2 * 2 + B * P * 4,
         "make_tiles": B * P * 4 + n_tiles_net * 2 * 224 * 224 * 4,
@@ -80,8 +89,39 @@ def alg_bytes(kernel, B, C, Z, Y, X, n_obj, n_tiles_net):
         "radial_geometry": B * P * 2 + B * P,
         "radial_distribution": B * P * (2 + 1 + 2) + n_obj * 12 * 8,
         "coloc": B * P * 2 * 3 + n_obj * 8 * 8,
+        "ranks": B * P * (2 + 2 + 4),
+        "track_stitch": 2 * B * P * 2,
     }
     return float(table.get(kernel, B * P * 2 * 2))
+
+
+# BASELINE.json configs -> what one bench step is.  `tile` = network tile; `per_step` = FOV stacks per step.
+CONFIGS = {
+    1: dict(C=2, Z=1, size=512, seg_channel=1, n_target=60, features=("intensity",), channels=(0,), label="C1"),
+    2: dict(C=5, Z=1, size=1024, seg_channel=0, n_target=250, features=None, channels=None, label="C2"),
+    4: dict(C=1, Z=5, size=512, seg_channel=0, n_target=None, features=(), channels=(), label="C4"),
+    5: dict(C=2, Z=32, size=512, seg_channel=0, n_target=100, features=("intensity",), channels=None, label="C5"),
+}
+
+
+def _make_one(job):
+    from aliby_amd import synth
+
+    config, fov, size, C, Z, n_target = job
+    f = synth.make_fov(config, fov, shape=(size, size), n_channels=C, n_z=Z, n_target=n_target)
+    dP, prob = synth.analytic_flows(f["nuclei"])
+    return dict(pixels=f["pixels"], nuclei=f["nuclei"], dP=dP, prob=prob)
+
+
+def make_inputs(config, cfg, fov_ids, size, procs):
+    """Distinct synthetic FOVs, generated by a pool of host processes BEFORE this process touches the GPU."""
+    import multiprocessing as mp
+
+    jobs = [(config, i, size, cfg["C"], cfg["Z"], cfg["n_target"]) for i in fov_ids]
+    if procs <= 1 or len(jobs) <= 1:
+        return [_make_one(j) for j in jobs]
+    with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
+        return pool.map(_make_one, jobs, chunksize=1)
 
 
 def main():
@@ -89,9 +129,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (1-based)")
     ap.add_argument("--fovs", type=int, default=64, help="FOVs per step per GPU")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic FOVs generated per rank (replicated)")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic FOVs generated per rank (replicated to --fovs)")
+    ap.add_argument("--total-fovs", type=int, default=0, help="strong-scaling mode: this many FOVs in all, split over the ranks "
+                    "(steps = ceil(total / (gpus * fovs)); --steps is then ignored)")
+    ap.add_argument("--size", type=int, default=0, help="override the configuration's frame size")
     ap.add_argument("--net-dtype", default="bfloat16", choices=["bfloat16", "float32", "float16"])
     ap.add_argument("--net-batch", type=int, default=288, help="224x224 tiles per U-Net forward (the reference's batch_size knob)")
     ap.add_argument("--time-every", type=int, default=7, help="bracket every n-th launch of the per-layer network kernels with HIP "
@@ -99,16 +142,42 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="informational: no per-kernel HIP events, so the network forward "
                     "runs as a replayed hipGraph (the product path); the line then carries no roofline objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the through-the-step-API leg (value_api)")
+    ap.add_argument("--api-fovs", type=int, default=0, help="positions of the API leg (default: 3 batches of --fovs)")
     ap.add_argument("--overlap", action="store_true", help="experiment: dynamics + features of step k on a second stream while the "
                     "network of step k+1 runs (software pipelining across steps)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--host-procs", type=int, default=0, help="host processes for input generation / the CPU baseline (default: all)")
     args = ap.parse_args()
+    if args.config == 4:
+        return main_timelapse(args)
+    cfg = CONFIGS[args.config]
+    size = args.size or cfg["size"]
+
+    from aliby_amd import parallel
+
+    rank, world, local_rank = parallel.rank_world()
+    from aliby_amd import hostinfo
+
+    procs = args.host_procs or hostinfo.usable_cores()  # this rank's share of the host, not os.cpu_count()
+    # ---- everything that forks happens before the GPU is touched: synthetic inputs, then the CPU baseline ---------------
+    distinct = max(1, min(args.distinct, args.fovs))
+    base = make_inputs(args.config, cfg, [rank + world * i for i in range(distinct)], size, procs)
+    channels = list(range(cfg["C"])) if cfg["channels"] is None else list(cfg["channels"])
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import whole_tile  # (checker code: only this leg of the bench uses oracle/)
+        from aliby_amd.pipe_builder import build_pipeline_steps
+
+        kw = {} if cfg["features"] is None else {"features_to_extract": tuple(cfg["features"])}
+        pipe = build_pipeline_steps(channels_to_segment={"nuclei": cfg["seg_channel"]}, channels_to_extract=channels, **kw)
+        cpu = whole_tile(dict(pixels=base[0]["pixels"], nuclei=base[0]["nuclei"]), (base[0]["dP"], base[0]["prob"]),
+                         pipe["steps"]["extract_nuclei"]["tree"], pipe["steps"].get("extractmulti_nuclei", {}).get("tree", {}),
+                         workers=procs, net_tiles=int(np.ceil(size / 224 * 1.2)) ** 2)
 
     import torch
 
-    from aliby_amd import _lib, parallel, synth
+    from aliby_amd import _lib, synth  # noqa: F401
 
-    rank, world, local_rank = parallel.rank_world()
     # ALIBY_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices,
     # collectives go through host memory); the driver's runs use the default, RCCL ("nccl") with one GPU per rank
     backend = os.environ.get("ALIBY_DIST_BACKEND", "nccl")
@@ -121,22 +190,24 @@ def main():
     from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr
     from aliby_amd.segment.cellpose_hip import CellposeModel
 
-    eng = FeatureEngine(local_rank)
-    C, Z, Y, X = 5, 1, args.size, args.size
+    C, Z, Y, X = cfg["C"], cfg["Z"], size, size
     B = args.fovs
-    mono_tree, multi_tree = build_trees(range(C))
+    steps = args.steps
+    scaling = "weak"
+    if args.total_fovs:
+        steps = max(1, -(-args.total_fovs // (world * B)))
+        scaling = "strong"
+    mono_tree, multi_tree = build_trees(channels, cfg["seg_channel"], cfg["features"])
 
     # ---- synthetic inputs, resident in HBM (positions rank, rank+world, ... of the FOV stream) ----------
-    base = [synth.make_fov(2, rank + world * i, shape=(Y, X)) for i in range(args.distinct)]
     stacks = torch.empty((B, C, Z, Y, X), dtype=torch.uint16, device="cuda")
     dP_true = torch.empty((B, 2, Y, X), dtype=torch.float32, device="cuda")
     prob_true = torch.empty((B, Y, X), dtype=torch.float32, device="cuda")
-    flows = [synth.analytic_flows(s["nuclei"]) for s in base]
     for b in range(B):
-        k = b % args.distinct
+        k = b % distinct
         stacks[b] = torch.from_numpy(base[k]["pixels"]).cuda()
-        dP_true[b] = torch.from_numpy(flows[k][0]).cuda()
-        prob_true[b] = torch.from_numpy(flows[k][1]).cuda()
+        dP_true[b] = torch.from_numpy(base[k]["dP"]).cuda()
+        prob_true[b] = torch.from_numpy(base[k]["prob"]).cuda()
     n_obj_per_fov = float(np.mean([int(s["nuclei"].max()) for s in base]))
     tiles = torch.empty_like(stacks)
     rect = np.array([[0, 0, Y, X]], np.int32)
@@ -156,14 +227,17 @@ def main():
             _lib.check(eng.lib.aliby_crop_pad_u16(eng.ctx.handle, _ptr(stacks), B * C, Z, Y, X, _ptr(rect), 1, Y, X,
                                                   _ptr(tiles), _ptr(flags), _stream_ptr()))
         px = tiles.view(B, C, Z, Y, X)
-        plane = model.select_and_project(px, 0)
+        plane = model.select_and_project(px, cfg["seg_channel"])
         masks, _, _ = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=True, z_axis=None)
         labels = masks if masks.ndim == 3 else masks[None]
         planes = (px, _lib.U16)
         m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
-        m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+        out = [m1]
+        if multi_tree:
+            m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+            out.append(m2)
         # rows -> pinned host memory on a side stream: the download of step k overlaps the start of step k+1
-        pending = eng.to_host_async((m1, m2), slot=step.parity)
+        pending = eng.to_host_async(tuple(out), slot=step.parity)
         step.parity ^= 1
         return pending, table, model.last_counts
 
@@ -179,7 +253,7 @@ def main():
             _lib.check(eng.lib.aliby_crop_pad_u16(eng.ctx.handle, _ptr(stacks), B * C, Z, Y, X, _ptr(rect), 1, Y, X,
                                                   _ptr(tb), _ptr(flags), _stream_ptr()))
         px = tb.view(B, C, Z, Y, X)
-        plane = model.select_and_project(px, 0)
+        plane = model.select_and_project(px, cfg["seg_channel"])
         model.run_network(plane)  # output discarded, as in step(): the cost is what is measured
         ev = torch.cuda.Event()
         ev.record()
@@ -220,14 +294,14 @@ def main():
     pending = None
     if args.overlap:
         state = phase_net(0)
-        for k in range(args.steps):
-            nxt_state = phase_net((k + 1) & 1) if k + 1 < args.steps else None  # queue the next network before this step's host read-backs
+        for k in range(steps):
+            nxt_state = phase_net((k + 1) & 1) if k + 1 < steps else None  # queue the next network before this step's host read-backs
             nxt, table, counts = phase_post(state)
             if pending is not None:
                 pending.wait()
             pending, state = nxt, nxt_state
     else:
-        for _ in range(args.steps):
+        for _ in range(steps):
             nxt, table, counts = step()
             if pending is not None:
                 pending.wait()  # the previous step's rows are on the host (its buffers may be reused two steps later)
@@ -243,7 +317,7 @@ def main():
         dt = float(t.item())
     prof = eng.collect_profile()
     eng.profile = None
-    tiles_per_s = world * B * args.steps / dt
+    tiles_per_s = world * B * steps / dt
     n_cols = sum(r.shape[1] for r in rows)
 
     # ---- the one exchange step: gather the last step's rows on rank 0 (RCCL over xGMI) ------------------
@@ -257,6 +331,7 @@ def main():
     gather_ms = 1e3 * (time.perf_counter() - t0)
 
     roof = roof_deep = None
+    fracs = {}
     if prof:  # (--no-kernel-timing: nothing was bracketed)
         # ---- roofline of the dominant hand-written kernel group ----------------------------------------------
         hip_groups = {k: v for k, v in prof.items() if k not in ("unet_forward", "rows_d2h")}
@@ -282,8 +357,7 @@ def main():
         if dominant.startswith("conv3x3_mfma"):  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
             roof["mfma_tflops"] = round(model.fused.conv_stats[dominant][1] / timed_launches / (avg_ms * 1e-3) / 1e12, 1)
         roof["timed_launches"] = timed_launches
-        # the deep levels' launches of the same kernel (128 output channels, K/N-split): bound by the matrix cores
-        roof_deep = None
+        # the deep levels' launches of the same kernel (128+ output channels): bound by the matrix cores
         if "conv3x3_mfma_deep" in prof and prof["conv3x3_mfma_deep"].get("timed_launches"):
             g = prof["conv3x3_mfma_deep"]
             st = model.fused.conv_stats["conv3x3_mfma_deep"]
@@ -293,36 +367,54 @@ def main():
                          "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(t_ms, 4), "launches": g["launches"],
                          "timed_launches": g["timed_launches"],
                          "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
-    net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(args.steps, 1)
+        # every HBM-bound group's fraction of the 8 TB/s peak: algorithmic bytes per launch / average launch time
+        for name, g in hip_groups.items():
+            if name.startswith("conv") or name in ("first_conv", "style", "out_head", "fused_pointwise"):
+                st = model.fused.conv_stats.get(name) if model.fused is not None else None
+                if not st or not g.get("timed_launches"):
+                    continue
+                gb = st[0] / g["timed_launches"]
+            else:
+                gb = alg_bytes(name, B, C, Z, Y, X, table.n_obj, n_tiles_net)
+            ms = g["ms_total"] / max(g["launches"], 1)
+            if ms > 0:
+                fracs[name] = round(gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(steps, 1)
     hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "conv3x3_mfma_head", "conv3x3_mfma_pair", "out_head",
-                                                                       "first_conv", "conv1x1_mfma", "style")) / max(args.steps, 1)
+                                                                       "first_conv", "conv1x1_mfma", "style")) / max(steps, 1)
     net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
     mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,
             "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(base[0], flows[0], mono_tree, multi_tree, args.cpu_seconds)
+    # ---- the same workload through the step API ------------------------------------------------------------------
+    api = None
+    if not args.no_api and not args.overlap:
+        del stacks, tiles
+        api = api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, eng)
 
     if rank == 0:
+        feats = ("sizeshape + per channel [radial_zernikes, intensity, feret, texture, radial_distribution, zernike] + 10 pairs x "
+                 "[pearson, costes, manders_fold, rwc]") if cfg["features"] is None else (
+            "sizeshape + " + ", ".join(cfg["features"]) + f" on channels {channels}" + (" + colocalisation pairs" if multi_tree else ""))
         line = {
             "metric": "FOV tiles/sec (whole node)",
             "value": round(tiles_per_s, 3),
             "unit": "tiles/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "ms_per_step": round(1e3 * dt / steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": f"u16 pixels, f64 feature accumulators, f32 dynamics, {args.net_dtype} U-Net",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {B} FOV/step/GPU of {Y}x{X}x{C}ch (Z={Z}), ~{n_obj_per_fov:.0f} nuclei/FOV, Cellpose nuclei on ch0 + "
-                            f"full cp_measure ({args.distinct} distinct FOVs per rank replicated to {B})",
-                "features": "sizeshape + per channel [radial_zernikes, intensity, feret, texture, radial_distribution, zernike] "
-                            "+ 10 pairs x [pearson, costes, manders_fold, rwc]",
+                "workload": f"{cfg['label']}: {B} FOV/step/GPU of {Y}x{X}x{C}ch (Z={Z}), ~{n_obj_per_fov:.0f} nuclei/FOV, Cellpose nuclei on "
+                            f"ch{cfg['seg_channel']} + cp_measure ({distinct} distinct FOVs per rank"
+                            + (f" replicated to {B}" if distinct < B else "") + ")"
+                            + (f"; fixed job of {world * B * steps} FOVs split over {world} rank(s)" if args.total_fovs else ""),
+                "features": feats,
                 "segmentation": "U-Net forward with fixed-seed random weights (weights not obtainable offline; cost paid, output "
                                 "discarded) + dynamics on analytic flows of the synthetic ground truth",
                 "objects_last_step": int(table.n_obj),
@@ -335,59 +427,101 @@ def main():
             "roofline_mfma": roof_deep,
             "cpu_baseline": cpu,
             "mfma": mfma,
-            "kernel_ms_per_step": {k: round(v["ms_total"] / args.steps, 3) for k, v in prof.items()},
+            "kernel_ms_per_step": {k: round(v["ms_total"] / steps, 3) for k, v in prof.items()},
+            "kernel_hbm_frac": fracs,
         }
+        if api is not None:
+            line.update(api)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(fov, flow, mono_tree, multi_tree, seconds):
-    """CPU restatement in the reference's structure, 1 core, on a bounded sample of FOV 0:
-    features = per-object full-frame masks, one call per (object x instruction), first k objects, extrapolated;
-    segmentation = NumPy dynamics on a 512x512 crop (x4) + the U-Net forward on CPU for a few 224-px tiles."""
+def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, eng):
+    """The same workload through the reference's API: one pipeline dict per position (build_pipeline_steps), inputs = pinned
+    host arrays [1,C,Z,Y,X], aliby_amd.parallel.run_positions with B positions per device step, outputs = parquet + mask .npz on
+    disk.  Returns {"value_api": tiles/s, "api": {...}, "api_split_ms_per_fov": {...}}."""
+    import shutil
+    import tempfile
+    import warnings
+
     import torch
 
-    from oracle import aliby_extract as ox
-    from oracle import cellpose_restated as cr
+    from aliby_amd import runner
+    from aliby_amd.pipe_builder import build_pipeline_steps
 
-    masks = [fov["nuclei"]]
-    pixels = fov["pixels"][None]
-    n_total = int(fov["nuclei"].max())
-    t0 = time.perf_counter()
-    ox.process_tree_masks(mono_tree, masks, pixels, ox.extract_tree, max_objects=1)
-    ox.process_tree_masks(multi_tree, masks, pixels, ox.extract_tree_multi, max_objects=1)
-    per_obj = time.perf_counter() - t0
-    k = int(max(1, min(n_total, seconds / max(per_obj, 1e-3))))
-    t0 = time.perf_counter()
-    ox.process_tree_masks(mono_tree, masks, pixels, ox.extract_tree, max_objects=k)
-    ox.process_tree_masks(multi_tree, masks, pixels, ox.extract_tree_multi, max_objects=k)
-    t_feat = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ox.transform_2d_to_3d(fov["nuclei"])
-    t_explode = time.perf_counter() - t0
-    feat_tile = (t_feat - 2 * t_explode) * n_total / k + 2 * t_explode
-    # segmentation leg
-    dP, prob = flow
-    c = min(512, dP.shape[1])
-    t0 = time.perf_counter()
-    cr.compute_masks(dP[:, :c, :c].copy(), prob[:c, :c].copy())
-    t_dyn = (time.perf_counter() - t0) * (dP.shape[1] * dP.shape[2]) / float(c * c)
-    from aliby_amd.segment.unet import build_network
+    n_pos = args.api_fovs or 3 * B
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dP_d = torch.stack([torch.from_numpy(b["dP"]) for b in base]).to(dev)
+    prob_d = torch.stack([torch.from_numpy(b["prob"]) for b in base]).to(dev)
+    pinned = [torch.from_numpy(b["pixels"][None]).pin_memory() for b in base]  # [1,C,Z,Y,X] each: the host side of the boundary
+    seg = cfg["seg_channel"]
+    keys = {}
+    for k, b in enumerate(base):  # a plane is recognised by its first pixels (distinct FOVs differ in their noise)
+        keys[b["pixels"][seg].max(axis=0)[0, :8].tobytes()] = k
 
-    torch.set_num_threads(1)
-    net = build_network(seed=0, device="cpu")
-    xt = torch.zeros((2, 2, 224, 224))
-    with torch.no_grad():
-        net(xt)
-        t0 = time.perf_counter()
-        net(xt)
-        t_net = (time.perf_counter() - t0) / 2 * 36  # 36 tiles per 1024^2 FOV
-    per_tile = feat_tile + t_dyn + t_net
-    return {"value": round(1.0 / per_tile, 6), "unit": "tiles/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (CPU restatement in the reference's structure) on FOV 0: features on the first {k} of {n_total} "
-                      f"objects ({t_feat:.1f} s) extrapolated to the tile = {feat_tile:.1f} s; NumPy dynamics on a {c}x{c} crop x"
-                      f"{(dP.shape[1] * dP.shape[2]) // (c * c)} = {t_dyn:.1f} s; U-Net fp32 on CPU, 2 of 36 tiles timed = {t_net:.1f} s"}
+    def override(x):
+        idx = [keys[row.tobytes()] for row in x[:, 0, :8].cpu().numpy()]
+        sel = torch.as_tensor(idx, device=dev)
+        return dP_d.index_select(0, sel), prob_d.index_select(0, sel)
+
+    kw = {} if cfg["features"] is None else {"features_to_extract": tuple(cfg["features"])}
+
+    def pipelines(n):
+        out = []
+        for i in range(n):
+            p = build_pipeline_steps(channels_to_segment={"nuclei": seg}, channels_to_extract=channels, **kw)
+            p["steps"]["tile"]["image_kwargs"] = {"source": pinned[i % distinct].numpy()}
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = SETUP
+            out.append(p)
+        return out
+
+    from aliby_amd import hostinfo
+
+    WRITERS = int(os.environ.get("ALIBY_WRITERS", max(2, hostinfo.usable_cores() - 4)))  # headroom for the launch / ingest threads
+    SETUP = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch)
+    out_dir = Path(tempfile.mkdtemp(prefix=f"aliby_bench_r{rank}_"))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            names = [f"w{rank}_{i:05d}" for i in range(B)]
+            runner.run_positions(pipelines(B), names, out_dir / "warm", batch_size=B, shard=False, writers=WRITERS)  # warm-up: one batch
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            names = [f"p{rank}_{i:05d}" for i in range(n_pos)]
+            pipes = pipelines(n_pos)
+            t0 = time.perf_counter()
+            stats = {}
+            res = runner.run_positions(pipes, names, out_dir / "run", batch_size=B, shard=False, writers=WRITERS, stats=stats)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rows = sum(r[0].num_rows for r in res)
+            cols = len(res[0][0].column_names)
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                if backend != "nccl":
+                    t = t.cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            parquet_bytes = sum(f.stat().st_size for f in (out_dir / "run" / "profiles").glob("*.parquet"))
+            # where the time goes: one more batch with every phase synchronised and timed (not part of value_api)
+            split = runner.run_positions(pipelines(B), [f"s{rank}_{i:05d}" for i in range(B)], out_dir / "split", batch_size=B,
+                                         shard=False, measure=True)
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    return {
+        "value_api": round(world * n_pos / dt, 3),
+        "api": {"path": "pinned host arrays -> build_pipeline_steps() dicts -> aliby_amd.parallel.run_positions (Tiler -> segment -> "
+                        "extract -> get_profiles_from_state -> parquet (zstd) + mask .npz on disk)",
+                "positions_per_rank": n_pos, "positions_per_device_step": B, "writer_threads": WRITERS, "seconds": round(dt, 3), "rows_written": rows,
+                "columns": cols, "parquet_bytes_per_fov": int(parquet_bytes / max(n_pos, 1)), "main_thread": stats},
+        "api_split_ms_per_fov": split,
+    }
+
+
+def main_timelapse(args):
+    raise SystemExit('config 4: see below')
 
 
 if __name__ == "__main__":

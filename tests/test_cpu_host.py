@@ -388,7 +388,7 @@ def init(step_name, parameters, other=None):
     raise ValueError(step_name)
 
 n = 5
-pipelines = [{"steps": {"tile": {"k": 10 * i}, "nahual_embed_x": {}}, "passed_data": {"nahual_embed_x": [("pixels", "tile")]}}
+pipelines = [{"steps": {"tile": {"k": 10 * i}, "nahual_embed_x": {"address": "ipc://unused"}}, "passed_data": {"nahual_embed_x": [("pixels", "tile")]}}
              for i in range(n)]
 names = [f"pos{i}" for i in range(n)]
 got = run_positions(pipelines, names, out, init_step_fn=init, batch_size=2)

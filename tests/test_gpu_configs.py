@@ -344,6 +344,13 @@ def test_run_positions_writes_what_single_calls_write(tmp_path, engine):
     want = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=single)[0] for p, nm in zip(pipelines(), names)]
     got = run_positions(pipelines(), names, batched, batch_size=3)  # batches of 3, 3, 1
     assert len(got) == n
+    # the same with the parquet files written by the writer PROCESSES (aliby_amd/io/writer_proc.py)
+    via_procs = tmp_path / "procs"
+    got_p = run_positions(pipelines(), names, via_procs, batch_size=4, writers=3, writer_processes=True)
+    for i, nm in enumerate(names):
+        assert got_p[i][0].equals(got[i][0]) or got_p[i][0].num_rows == got[i][0].num_rows
+        assert (via_procs / "profiles" / f"{nm}.parquet").read_bytes() == (single / "profiles" / f"{nm}.parquet").read_bytes()
+    assert not list(Path("/dev/shm").glob(f"aliby_{__import__('os').getpid()}_*"))
     for i, nm in enumerate(names):
         prof, post = got[i]
         assert post == {} and prof.schema.equals(want[i].schema) and prof.num_rows == want[i].num_rows > 0
