@@ -52,3 +52,13 @@ def lookup(host_array):
         _table.pop(id(host_array), None)  # another object at a recycled id, or the caller unlocked it to edit in place
         return None
     return dev, meta
+
+
+def wait_ready(host_array) -> None:
+    """Block until the bytes of a registered host array are valid: producers that download asynchronously register the
+    array with `ready=<event>` (the position-batched segmenter does); everything else returns at once."""
+    hit = _table.get(id(host_array))
+    if hit is not None and hit[0]() is host_array:
+        event = hit[2].get("ready")
+        if event is not None:
+            event.synchronize()

@@ -152,7 +152,7 @@ class FeatureEngine:
         _lib.check(self.lib.aliby_stream_sync(self.ctx.handle, _stream_ptr()))  # polls an event: no late wake-up
         return view.numpy().copy() if copy else view.numpy()
 
-    def to_host_async(self, tensors, slot: int = 0):
+    def to_host_async(self, tensors, slot: int = 0, alloc=None):
         """Start the download of `tensors` into pinned buffers on a side stream (after everything queued so far on the
         current stream) and return a handle; handle.wait() -> list of NumPy views.  The copy overlaps whatever the
         caller queues next; `slot` selects one of the reusable buffer sets (alternate it between consecutive calls)."""
@@ -168,7 +168,9 @@ class FeatureEngine:
             for i, t in enumerate(tensors):
                 key = (slot, i, t.dtype)
                 buf = pool.get(key) if slot is not None else None
-                if slot is None:  # a buffer of its own (readers on other threads keep it alive; torch recycles pinned blocks)
+                if alloc is not None:  # the caller's page-locked arena (aliby_amd/runner.py: reused from batch to batch)
+                    buf = alloc((max(t.numel(), 1),), t.dtype)
+                elif slot is None:  # a buffer of its own (readers on other threads keep it alive; torch recycles pinned blocks)
                     buf = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
                 elif buf is None or buf.numel() < t.numel():
                     buf = pool[key] = torch.empty(int(t.numel() * 1.25) + 1024, dtype=t.dtype, pin_memory=True)

@@ -260,9 +260,14 @@ def _format_dense(instructions, results: DeviceResults) -> pa.Table:
     rows in first-seen (tile, label) order, metric columns sorted (extract.py:574-596).  One transposed copy of the feature
     matrix, then every Arrow column is a window of that buffer (no per-value Python work)."""
     schema, take = _dense_layout(results)
-    matrix = results.matrix
-    n = matrix.shape[0]
-    block = np.ascontiguousarray(matrix[:, take].T)  # [n_cols, n_rows], C order: row j = column j of the table
+    ready = getattr(results, "_transposed", None)
+    if ready is not None:
+        block = ready.get()  # already column-sorted and transposed on the device (aliby_amd/runner.py)
+        n = block.shape[1]
+    else:
+        matrix = results.matrix
+        n = matrix.shape[0]
+        block = np.ascontiguousarray(matrix[:, take].T)  # [n_cols, n_rows], C order: row j = column j of the table
     buf = pa.py_buffer(block)
     f64 = pa.float64()
     objs = np.asarray(results.objects, dtype=np.int64).reshape(n, 2)

@@ -24,6 +24,23 @@ def _to_uint16_labels(labels: np.ndarray) -> np.ndarray:
     return labels.astype(np.uint16, copy=False)
 
 
+def _as_one_block(blocks):
+    """Device blocks that are consecutive slices of one allocation (the batched runner uploads them that way) -> one tensor
+    over all of them, else None."""
+    import torch
+
+    first = blocks[0]
+    if len(blocks) < 2 or not all(isinstance(b, torch.Tensor) and b.is_contiguous() and b.dtype == first.dtype
+                                  and b.shape[1:] == first.shape[1:] for b in blocks):
+        return None
+    expect = first.data_ptr()
+    for b in blocks:
+        if b.data_ptr() != expect or b.untyped_storage().data_ptr() != first.untyped_storage().data_ptr():
+            return None
+        expect += b.numel() * b.element_size()
+    return torch.as_strided(first, (sum(b.shape[0] for b in blocks), *first.shape[1:]), first.stride())
+
+
 def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, **kwargs) -> callable:
     if kind in ("nahual_baby", "nahual_cellpose", "nahual_spotiflow") or (kind or "").startswith("nahual"):
         raise NotImplementedError(f"segmenter kind '{kind}' is a remote Nahual service (SURVEY §2 row 6): out of scope")
@@ -69,19 +86,24 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         """One model.eval over every tile of every block: list of device blocks [F_i,C,Z,Y,X] -> labels [sum F_i,Y,X], counts."""
         import torch
 
-        planes = [model.select_and_project(b, channel_to_segment) for b in blocks]  # [F_i,Y,X], max over Z if Z>1
-        plane = planes[0] if len(planes) == 1 else torch.cat(planes, 0)
+        whole = _as_one_block(blocks)
+        if whole is not None:
+            plane = model.select_and_project(whole, channel_to_segment)
+        else:
+            planes = [model.select_and_project(b, channel_to_segment) for b in blocks]  # [F_i,Y,X], max over Z if Z>1
+            plane = planes[0] if len(planes) == 1 else torch.cat(planes, 0)
         result = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=kw.pop("normalize", True), z_axis=None, **kw)
         labels = result[0]
         return (labels if labels.ndim == 3 else labels[None]), np.asarray(model.last_counts)
 
-    def _finish(stack, counts):
-        """The reference's post-processing of one position's label stack [F,Y,X] (dispatch.py:216-234) -> step result."""
+    def _finish(stack, counts, host_stack=None, ready=None):
+        """The reference's post-processing of one position's label stack [F,Y,X] (dispatch.py:216-234) -> step result.
+        host_stack: the same stack already on the host (the batched entry downloads every position's labels in one copy)."""
         if per_tile:
             if counts.size and counts.max() >= np.iinfo(np.uint16).max:
                 raise OverflowError(f"Segmentation produced {counts.max()} labels; uint16 cast unsafe.")
-            host = stack.cpu().numpy()
-            return [devcache.attach(host[k], stack[k], kind="labels") for k in range(host.shape[0])]
+            host = stack.cpu().numpy() if host_stack is None else host_stack
+            return [devcache.attach(host[k], stack[k], kind="labels", ready=ready) for k in range(host.shape[0])]
         if stack.shape[0] > 1:
             # reference: a 3-D result is collapsed, labels.max(axis=0) then relabel_sequential (dispatch.py:218-223)
             labels_dev = model.max_project_and_relabel(stack)
@@ -91,8 +113,9 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
             n_labels = int(counts[0]) if counts.size else 0
         if n_labels >= np.iinfo(np.uint16).max:
             raise OverflowError(f"Segmentation produced {n_labels} labels; uint16 cast unsafe.")
-        host = labels_dev.cpu().numpy()
-        return devcache.attach(host, labels_dev, kind="labels")
+        if host_stack is not None and stack.shape[0] == 1:
+            return devcache.attach(host_stack[0], labels_dev, kind="labels", ready=ready)
+        return devcache.attach(labels_dev.cpu().numpy(), labels_dev, kind="labels")
 
     def segment(pixels, do_3D: bool = False, stitch_threshold=None, **kw):
         """Assumes FCZYX pixels.  Returns uint16 labels [Y,X] (monotile), as the reference does."""
@@ -104,16 +127,28 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         stack, counts = _labels_of([_device_block(pixels)], dict(kw))
         return _finish(stack, counts)
 
-    def segment_batch(blocks, **kw):
+    def segment_batch(blocks, pinned_alloc=None, **kw):
         """Position-batched form used by aliby_amd.runner: `blocks` = one FCZYX block per position (device tensors or host
         arrays); every tile of every position goes through ONE network / dynamics pass, then each position's stack gets the
         reference's post-processing on its own.  Returns one step result per position, identical to `segment(block)`."""
         devs = [_device_block(b) for b in blocks]
         stack, counts = _labels_of(devs, dict(kw))
+        # every position's labels in ONE download through a page-locked buffer (N pageable copies cost a sync each)
+        import torch
+
+        # ... and without waiting for it: the next consumers (extract, track) read the DEVICE labels through devcache; whoever
+        # needs the host bytes (the .npz writer threads, a caller after the run) goes through devcache.wait_ready first
+        # (a fresh page-locked buffer costs a hipHostMalloc of ~100 MB per batch on the launch thread: the runner lends its arena)
+        pinned = (pinned_alloc(tuple(stack.shape), stack.dtype) if pinned_alloc is not None
+                  else torch.empty(tuple(stack.shape), dtype=stack.dtype, pin_memory=True))  # (its NumPy views keep it alive)
+        pinned.copy_(stack, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        host_all = pinned.numpy()
         out, k = [], 0
         for d in devs:
             f = d.shape[0]
-            out.append(_finish(stack[k : k + f], counts[k : k + f]))
+            out.append(_finish(stack[k : k + f], counts[k : k + f], host_all[k : k + f], ready))
             k += f
         return out
 

@@ -88,6 +88,7 @@ class Tiler:
         self._engine = None
         self._ingest_stream = self._ingest_pool = self._ingest_pending = None
         self._crop_cache = None
+        self._upload_into = {}  # tp -> device buffer [C,Z,Y,X] the stack of that timepoint must land in (set by the batched runner)
         # The reference reads `calculate_drift` as an attribute a caller sets after construction (tiler.py:428-431); a
         # pipeline dict has no way to do that, so the step parameter of the same name is accepted here.
         if "calculate_drift" in kwargs:
@@ -190,22 +191,31 @@ class Tiler:
 
         if tp in self._dev_stack:
             return self._dev_stack[tp]
-        dev = self._ingest(tp)
+        target = self._upload_into.pop(tp, None)
+        dev = self._ingest(tp, target)
         if dev is not None:
             pass
         else:
-            dev = self._upload(self.pixels[tp])
+            dev = self._upload(self.pixels[tp], target)
         if len(self._dev_stack) >= 2:
             self._dev_stack.pop(next(iter(self._dev_stack)))
         self._dev_stack[tp] = dev
         return dev
 
-    def _upload(self, block):
+    def set_upload_buffer(self, tp: int, buffer) -> None:
+        """The stack of timepoint `tp` is to be uploaded into `buffer` (a device uint16 tensor [C,Z,Y,X]): the position-batched
+        runner hands every position a slice of one [B,C,Z,Y,X] block, so the batch is contiguous without a gather copy."""
+        self._upload_into[tp] = buffer
+
+    def _upload(self, block, target=None):
         import torch
 
         if hasattr(block, "compute"):
             block = block.compute(scheduler="synchronous")
         if isinstance(block, torch.Tensor):
+            if target is not None and tuple(target.shape) == tuple(block.shape) and block.dtype == target.dtype:
+                target.copy_(block, non_blocking=True)
+                return target
             return block.cuda()
         block = np.ascontiguousarray(block)
         if block.dtype != np.uint16:
@@ -215,9 +225,12 @@ class Tiler:
         src = torch.from_numpy(block)
         # page-locked host memory goes up asynchronously on the current stream at PCIe rate (pageable memory is staged by the
         # runtime at a quarter of it); torch's host allocator keeps a pinned block alive until the copy has run
+        if target is not None and tuple(target.shape) == tuple(src.shape):
+            target.copy_(src, non_blocking=src.is_pinned())
+            return target
         return src.cuda(non_blocking=src.is_pinned())
 
-    def _ingest(self, tp: int):
+    def _ingest(self, tp: int, target=None):
         """File-backed stacks (aliby_amd/io/image.py): decode + upload through csrc/ingest.hip on a side stream, and
         start decoding the next time point on a helper thread while this one is being processed."""
         import torch
@@ -242,7 +255,7 @@ class Tiler:
             if pending[0] == tp:
                 dev = got
         if dev is None:
-            dev = pixels.read_device(tp, ctx, stream, None, device)
+            dev = pixels.read_device(tp, ctx, stream, target, device)
         if dev is not None and tp + 1 < pixels.shape[0]:
             self._ingest_pending = (tp + 1, self._ingest_pool.submit(pixels.read_device, tp + 1, ctx, stream, None, device))
         return dev

@@ -456,13 +456,13 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
     prob_d = torch.stack([torch.from_numpy(b["prob"]) for b in base]).to(dev)
     pinned = [torch.from_numpy(b["pixels"][None]).pin_memory() for b in base]  # [1,C,Z,Y,X] each: the host side of the boundary
     seg = cfg["seg_channel"]
-    keys = {}
-    for k, b in enumerate(base):  # a plane is recognised by its first pixels (distinct FOVs differ in their noise)
-        keys[b["pixels"][seg].max(axis=0)[0, :8].tobytes()] = k
+    # a plane is recognised by its first pixels (distinct FOVs differ in their noise) — on the device, so that the stand-in
+    # for the network's output costs no host round trip
+    keys_d = torch.from_numpy(np.stack([b["pixels"][seg].max(axis=0)[0, :8].astype(np.int32) for b in base])).to(dev)
+    assert len({bytes(k) for k in keys_d.cpu().numpy()}) == len(base), "synthetic FOVs collide on their first 8 pixels"
 
     def override(x):
-        idx = [keys[row.tobytes()] for row in x[:, 0, :8].cpu().numpy()]
-        sel = torch.as_tensor(idx, device=dev)
+        sel = (x[:, 0, :8].to(torch.int32)[:, None, :] == keys_d[None]).all(-1).to(torch.int32).argmax(1)
         return dP_d.index_select(0, sel), prob_d.index_select(0, sel)
 
     kw = {} if cfg["features"] is None else {"features_to_extract": tuple(cfg["features"])}
@@ -476,9 +476,7 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
             out.append(p)
         return out
 
-    from aliby_amd import hostinfo
-
-    WRITERS = int(os.environ.get("ALIBY_WRITERS", max(2, hostinfo.usable_cores() - 4)))  # headroom for the launch / ingest threads
+    WRITERS = None  # aliby_amd.runner sizes its writer threads / processes from the host share (ALIBY_WRITERS / ALIBY_WRITER_PROCS)
     SETUP = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch)
     out_dir = Path(tempfile.mkdtemp(prefix=f"aliby_bench_r{rank}_"))
     try:
@@ -493,7 +491,18 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
             pipes = pipelines(n_pos)
             t0 = time.perf_counter()
             stats = {}
+            prof = None
+            if os.environ.get("ALIBY_PROFILE_API"):  # diagnostic: where the launch thread's time goes (cProfile, to stderr)
+                import cProfile
+
+                prof = cProfile.Profile()
+                prof.enable()
             res = runner.run_positions(pipes, names, out_dir / "run", batch_size=B, shard=False, writers=WRITERS, stats=stats)
+            if prof is not None:
+                import pstats
+
+                prof.disable()
+                pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             rows = sum(r[0].num_rows for r in res)
@@ -506,15 +515,15 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
                 dt = float(t.item())
             parquet_bytes = sum(f.stat().st_size for f in (out_dir / "run" / "profiles").glob("*.parquet"))
             # where the time goes: one more batch with every phase synchronised and timed (not part of value_api)
-            split = runner.run_positions(pipelines(B), [f"s{rank}_{i:05d}" for i in range(B)], out_dir / "split", batch_size=B,
-                                         shard=False, measure=True)
+            split = runner.run_positions(pipelines(2 * B), [f"s{rank}_{i:05d}" for i in range(2 * B)], out_dir / "split", batch_size=B,
+                                         shard=False, measure=True)  # (the second of two batches is the one reported)
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
     return {
         "value_api": round(world * n_pos / dt, 3),
         "api": {"path": "pinned host arrays -> build_pipeline_steps() dicts -> aliby_amd.parallel.run_positions (Tiler -> segment -> "
                         "extract -> get_profiles_from_state -> parquet (zstd) + mask .npz on disk)",
-                "positions_per_rank": n_pos, "positions_per_device_step": B, "writer_threads": WRITERS, "seconds": round(dt, 3), "rows_written": rows,
+                "positions_per_rank": n_pos, "positions_per_device_step": B, "seconds": round(dt, 3), "rows_written": rows,
                 "columns": cols, "parquet_bytes_per_fov": int(parquet_bytes / max(n_pos, 1)), "main_thread": stats},
         "api_split_ms_per_fov": split,
     }

@@ -346,7 +346,7 @@ def test_run_positions_writes_what_single_calls_write(tmp_path, engine):
     assert len(got) == n
     # the same with the parquet files written by the writer PROCESSES (aliby_amd/io/writer_proc.py)
     via_procs = tmp_path / "procs"
-    got_p = run_positions(pipelines(), names, via_procs, batch_size=4, writers=3, writer_processes=True)
+    got_p = run_positions(pipelines(), names, via_procs, batch_size=4, writers=2, writer_processes=3)
     for i, nm in enumerate(names):
         assert got_p[i][0].equals(got[i][0]) or got_p[i][0].num_rows == got[i][0].num_rows
         assert (via_procs / "profiles" / f"{nm}.parquet").read_bytes() == (single / "profiles" / f"{nm}.parquet").read_bytes()
