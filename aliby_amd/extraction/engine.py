@@ -116,11 +116,16 @@ class _Timer:
     def __exit__(self, *exc):
         b = torch.cuda.Event(enable_timing=True)
         b.record()
-        self.eng.profile.setdefault(self.name, []).append((self.a, b))
+        self.eng._profile().setdefault(self.name, []).append((self.a, b))
         return False
 
 
 class FeatureEngine:
+    shared_profile = None  # set to {} to time the kernel groups of EVERY engine of the process (steps build their own engines)
+
+    def _profile(self):
+        return self.profile if self.profile is not None else FeatureEngine.shared_profile
+
     def __init__(self, device: int | None = None):
         if not torch.cuda.is_available():
             raise _lib.AlibyHipError("no GPU visible: the HIP feature engine has no CPU fallback")
@@ -187,7 +192,7 @@ class FeatureEngine:
         kernel is launched on) when profiling is enabled.  Groups listed in `profile_sample` (name -> n) are
         launched hundreds of times per step: only every n-th launch is bracketed (two event records per launch
         would otherwise perturb what they measure); `collect_profile` scales the sampled average to all launches."""
-        if self.profile is None:
+        if self._profile() is None:
             return _NO_TIMER
         every = self.profile_sample.get(name, 1)
         if every > 1:
@@ -200,7 +205,7 @@ class FeatureEngine:
     def collect_profile(self) -> dict:
         torch.cuda.synchronize()
         out = {}
-        for name, evs in (self.profile or {}).items():
+        for name, evs in (self._profile() or {}).items():
             timed_ms = float(sum(a.elapsed_time(b) for a, b in evs))
             launches = self._sample_count.get(name, len(evs)) if self.profile_sample.get(name, 1) > 1 else len(evs)
             out[name] = {"ms_total": timed_ms * launches / max(len(evs), 1), "launches": launches, "timed_launches": len(evs)}

@@ -60,6 +60,13 @@ def dispatch_tiler(kind, kwargs: dict):
     return partial(Tiler.from_image, parameters=TilerParameters(**tiler_kwargs), **extra)
 
 
+def _plane_of(pixels, tp, c, z):
+    """One YX plane of a TCZYX stack: a device tensor stays one (the drift estimate runs on the GPU anyway), anything else
+    becomes a NumPy array as in the reference (tiler.py:296-303)."""
+    plane = pixels[tp, c, z]
+    return plane if type(plane).__module__.startswith("torch") else np.asarray(plane)
+
+
 def get_center(pixels_shape):
     yx = tuple(pixels_shape[-2:])
     return TileLocations.from_tiler_init((tuple(s // 2 for s in yx),), max_size=yx)
@@ -126,10 +133,8 @@ class Tiler:
 
         ref_z = getattr(self, "ref_z", 0)
         prev_tp = max(0, tp - 1)
-        drift = phase_cross_correlation(
-            np.asarray(self.pixels[prev_tp, self.ref_channel_index, ref_z]),
-            np.asarray(self.pixels[tp, self.ref_channel_index, ref_z]),
-        )
+        drift = phase_cross_correlation(_plane_of(self.pixels, prev_tp, self.ref_channel_index, ref_z),
+                                        _plane_of(self.pixels, tp, self.ref_channel_index, ref_z))
         if 0 < tp < len(self.tile_locs.drifts):
             self.tile_locs.drifts[tp] = drift.tolist()
         else:
@@ -176,7 +181,9 @@ class Tiler:
                 from aliby_amd.tile.traps import segment_traps
 
                 try:
-                    initial = np.asarray(self.pixels[0, self.ref_channel_index, getattr(self, "ref_z", 0)])
+                    initial = _plane_of(self.pixels, 0, self.ref_channel_index, getattr(self, "ref_z", 0))
+                    if not isinstance(initial, np.ndarray):
+                        initial = initial.cpu().numpy()  # (a stack that already lives on the device)
                     found = segment_traps(initial, tmin)
                 except Exception as e:
                     warnings.warn(f"Trap detection failed ({e}), falling back to center tile.")

@@ -530,7 +530,194 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
 
 
 def main_timelapse(args):
-    raise SystemExit('config 4: see below')
+    """Config 4 (BASELINE.json configs[3]): yeast time-lapse positions, T x [1, 5, 512, 512], 117-px trap tiles — trap
+    detection on the first frame, drift per timepoint, per-tile segmentation, IoU tracking, sizeshape — through the step API
+    (aliby_amd.parallel.run_positions), B positions in lockstep.  A step = one timepoint of every position of the batch;
+    a tile = one 117x117 trap window of one timepoint.  Inputs are device tensors (resident in HBM before the clock starts)."""
+    import shutil
+    import tempfile
+    import warnings
+
+    from aliby_amd import hostinfo, parallel, synth
+
+    rank, world, local_rank = parallel.rank_world()
+    B = args.fovs if args.fovs != 64 else 16
+    K, W = max(args.steps, 2), max(args.warmup, 1)
+    T = K + W
+    tl = synth.make_timelapse(T=T, seed=11 + rank)
+    half, tile = 117 // 2, 117
+    tree = {"None": {"None": ["sizeshape"]}}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_timelapse(tl, tree, min(T, 6))
+
+    import torch
+
+    backend = os.environ.get("ALIBY_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_rank)
+    parallel.init(backend if world > 1 else None)
+    dist = torch.distributed if world > 1 else None
+    from aliby_amd import runner
+    from aliby_amd.extraction.engine import FeatureEngine
+    from aliby_amd.tile.tiles import TileLocations
+
+    frames = torch.from_numpy(tl["pixels"]).cuda()  # [T,1,5,512,512]
+    # analytic network-scale flows of the ground truth, per timepoint, cropped at the windows the tiler will use
+    dP_full, prob_full = [], []
+    for t in range(T):
+        d, p = synth.analytic_flows(tl["labels"][t])
+        dP_full.append(torch.from_numpy(d))
+        prob_full.append(torch.from_numpy(p))
+    dP_full, prob_full = torch.stack(dP_full).cuda(), torch.stack(prob_full).cuda()
+    clock = {"calls": 0, "t0": 0, "n": B}
+    state = {}
+
+    def override(x):  # x [B*F,117,117]: every position is the same sample, so one set of windows serves the batch
+        t = clock["t0"] + clock["calls"]
+        clock["calls"] += 1
+        tiler = state["tiler"]
+        rects = tiler.rects(t)
+        dP = torch.stack([dP_full[t, :, y : y + h, x0 : x0 + w] for y, x0, h, w in rects])
+        pr = torch.stack([prob_full[t, y : y + h, x0 : x0 + w] for y, x0, h, w in rects])
+        reps = x.shape[0] // dP.shape[0]
+        return dP.repeat(reps, 1, 1, 1), pr.repeat(reps, 1, 1)
+
+    setup = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch)
+
+    def pipelines(t0, ntps):
+        out = []
+        for i in range(B):
+            out.append({
+                "ntps": ntps,
+                "steps": {
+                    "tile": {"image_kwargs": {"source": frames[t0 : t0 + ntps]}, "tile_size": tile, "ref_channel": 0, "calculate_drift": True},
+                    "segment_cells": {"segmenter_kwargs": {"kind": "cellpose", "per_tile": True, "setup_params": setup}, "channel_to_segment": 0},
+                    "track": {"kind": "stitch", "stitch_threshold": 0.25},
+                    "extract_cells": {"tree": tree},
+                },
+                "passed_data": {"track": [("masks", "segment_cells"), ("track_info", "track")],
+                                "extract_cells": [("masks", "segment_cells"), ("pixels", "tile")]},
+                "passed_methods": {"segment_cells": ("tile", "get_fczyx")},
+                "save": ("segment_cells",), "save_interval": 1, "retain": {"tile": 1, "segment_cells": 2},
+            })
+        return out
+
+    class _Spy:  # the override needs the windows of the batch's first tiler
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, name, params, other=None):
+            made = self.fn(name, params, other)
+            if name == "tile" and "tiler" not in state:
+                state["tiler"] = made
+            return made
+
+    from aliby_amd.pipe import init_step
+
+    out_dir = Path(tempfile.mkdtemp(prefix=f"aliby_bench4_r{rank}_"))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            clock.update(calls=0, t0=0)
+            runner.run_positions(pipelines(0, W), [f"w{i}" for i in range(B)], out_dir / "warm", batch_size=B, shard=False,
+                                 init_step_fn=_Spy(init_step))
+            state.clear()
+            FeatureEngine.shared_profile = None if args.no_kernel_timing else {}
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            clock.update(calls=0, t0=W)
+            t0 = time.perf_counter()
+            res = runner.run_positions(pipelines(W, K), [f"p{i}" for i in range(B)], out_dir / "run", batch_size=B, shard=False,
+                                       init_step_fn=_Spy(init_step))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        n_tiles = len(state["tiler"].tile_locs)
+        rows = sum(r[0].num_rows for r in res)
+        prof = FeatureEngine(local_rank).collect_profile() if FeatureEngine.shared_profile is not None else {}
+        FeatureEngine.shared_profile = None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if backend != "nccl":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tiles_per_s = world * B * K * n_tiles / dt
+    roof, fracs = None, {}
+    if prof:
+        F = B * n_tiles
+        for name, g in prof.items():
+            if name in ("unet_forward",) or name.startswith("conv") or name in ("first_conv", "style", "out_head"):
+                continue
+            gb = alg_bytes(name, F, 1, 5 if name in ("stage_crop_pad", "select_project", "reduce_z") else 1, tile, tile, rows // max(K, 1), 0)
+            ms = g["ms_total"] / max(g["launches"], 1)
+            if ms > 0:
+                fracs[name] = (round(gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), g["ms_total"], ms, gb, g["launches"])
+        if fracs:
+            dominant = max(fracs, key=lambda k: fracs[k][1])
+            fr, _, ms, gb, launches = fracs[dominant]
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(gb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": fr, "traffic": None, "alg_bytes_per_launch": gb, "avg_launch_ms": round(ms, 4), "launches": launches,
+                    "note": "117-px tiles: a launch moves ~10 MB, so every kernel of this configuration is launch-latency bound"}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "FOV tiles/sec (whole node)", "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"u16 pixels, f64 feature accumulators, f32 dynamics, {args.net_dtype} U-Net", "data": "synthetic",
+            "config": {"workload": f"C4: {B} time-lapse positions/GPU in lockstep, T={K} timed timepoints of [1,5,512,512], {n_tiles} trap tiles "
+                                   f"of 117x117 per position (detected on the first frame), drift per timepoint, per-tile Cellpose, IoU tracking, "
+                                   "sizeshape; through the step API (run_positions), stacks resident in HBM",
+                       "segmentation": "U-Net forward with fixed-seed random weights (cost paid, output discarded) + dynamics on analytic flows",
+                       "rows_written": rows, "feature_vectors_per_s": round(world * rows / dt, 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernel_ms_per_step": {k: round(v["ms_total"] / K, 3) for k, v in prof.items()},
+            "kernel_hbm_frac": {k: v[0] for k, v in fracs.items()},
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_timelapse(tl, tree, n_tp):
+    """Config 4 on one core: the CPU restatement of trap detection (once), then per timepoint drift, tile windows, NumPy
+    dynamics per tile, IoU stitching and sizeshape through the reference-structured extraction — n_tp timepoints timed."""
+    from oracle import aliby_extract as ox
+    from oracle import cellpose_restated as cr
+    from oracle import tiler_ref
+    from oracle.cpu_baseline import cpu_model
+    from oracle.drift_restated import phase_cross_correlation as pcc
+    from oracle.track_restated import stitch_rois
+    from oracle.traps_restated import segment_traps
+    from aliby_amd import synth
+
+    frames, half, tile = tl["pixels"], 117 // 2, 117
+    t0 = time.perf_counter()
+    centres = [c for c in segment_traps(frames[0, 0, 0], tile) if half < c[0] < 512 - half and half < c[1] < 512 - half]
+    t_traps = time.perf_counter() - t0
+    drifts, prev, info = [], None, None
+    t0 = time.perf_counter()
+    for t in range(n_tp):
+        drifts.append(pcc(frames[max(0, t - 1), 0, 0], frames[t, 0, 0]).tolist())
+        cum = np.sum(drifts, axis=0)
+        ranges = []
+        for cy, cx in centres:
+            y, x = (np.array([cy, cx]) - cum).astype(int)
+            ranges.append((slice(int(y) - half, int(y) - half + tile), slice(int(x) - half, int(x) - half + tile)))
+        px = tiler_ref.get_fczyx(frames[t], ranges)
+        masks = [cr.finish_labels(cr.compute_masks(*synth.analytic_flows(tiler_ref.relabel_sequential(tl["labels"][t][r])))) for r in ranges]
+        if prev is not None:
+            info = stitch_rois([[a, b] for a, b in zip(prev, masks)], info)
+        prev = masks
+        ox.process_tree_masks(tree, masks, px, ox.extract_tree)
+    per_tp = (time.perf_counter() - t0) / n_tp
+    n_tiles = len(centres)
+    return {"value": round(n_tiles / per_tp, 4), "unit": "tiles/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+            "os_cpu_count": os.cpu_count(),
+            "sample": f"oracle (CPU restatement) on one position: {n_tp} timepoints x {n_tiles} tiles, {per_tp:.2f} s per timepoint "
+                      f"(drift + windows + NumPy dynamics per tile + IoU stitching + sizeshape on full-tile masks); trap detection once "
+                      f"{t_traps:.1f} s (not in the rate); the network forward is not part of this CPU figure"}
 
 
 if __name__ == "__main__":
