@@ -71,6 +71,9 @@ _SIGNATURES = {
     "aliby_average_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "aliby_nn_fused_act_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "aliby_nn_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "aliby_nn_conv3x3_deep_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "aliby_nn_maxpool2_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "aliby_debug_conv_deep_trace": (_i, [_vp, _vp]),
     "aliby_track_stitch": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),
     "aliby_debug_conv_trace": (_i, [_vp, _vp]),
     "aliby_features_coloc_pairs": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, C.c_double, C.c_double, _vp, _vp, _vp]),

@@ -83,6 +83,8 @@ class FusedUNet:
         self.mfma_levels = tuple(mfma_levels)
         self.fused_head = os.environ.get("ALIBY_NET_FUSED_HEAD", "1") != "0"
         self.fused_pair = os.environ.get("ALIBY_NET_FUSED_PAIR", "1") != "0"  # level 0: conv2 + conv3 of a block in one launch
+        # deep levels (128 / 256 channels): one K-loop launch per convolution (csrc/nn_conv_deep.hip); 0 = the K/N-slice launches
+        self.deep_kernel = os.environ.get("ALIBY_CONV_DEEP", "1") != "0"
         self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
         self.lib, self.h = eng.lib, eng.ctx.handle
         net = net.float().eval()
@@ -175,6 +177,12 @@ class FusedUNet:
         H, W = (x.shape[2] * 2, x.shape[3] * 2) if in_up else (x.shape[2], x.shape[3])
         out = self._new(n, cout, H, W)
         pooled = self._new(n, cout, H // 2, W // 2) if pool else None
+        if self.deep_kernel and cout % 128 == 0 and cin in (64, 128, 256) and W <= 56 and (H + 1) * (W + 2) >= 226 + 2 * (W + 2):
+            self._launch_deep(x, unit, out, shift, bias, res, res_up, in_up)
+            if pool:
+                with self.eng.timed("maxpool"):
+                    _lib.check(self.lib.aliby_nn_maxpool2_bf16(self.h, _ptr(out), _ptr(pooled), n, H, W, cout, _stream_ptr()))
+            return (out, pooled) if pool else out
         if (cin, cout, bool(in_up)) in (_POOL_SHAPES if pool else _MFMA_SHAPES):
             self._launch_unit(x, unit, (0, cin), (0, cout), out, shift, bias, res, res_up, in_up, pooled)
             return (out, pooled) if pool else out
@@ -281,6 +289,23 @@ class FusedUNet:
                 self.h, _ptr(x), _ptr(unit.wpk[key]), _ptr(out), _ptr(unit.scale), _ptr(sh), self._sps(sh), _ptr(bias), n, H, W, cin, cout,
                 _ptr(x_in), _ptr(proj.wpk), x_in.shape[1], _stream_ptr()))
         return out
+
+    def _launch_deep(self, x, unit, out, shift, bias, res, res_up, in_up):
+        """One launch of the K-loop kernel (aliby_nn_conv3x3_deep_bf16): fp32 accumulation over the whole 9 * CIN reduction."""
+        n, cin, cout = x.shape[0], x.shape[1], out.shape[1]
+        H, W = out.shape[2], out.shape[3]
+        sh = unit.shift if shift is None else shift
+        group = "conv3x3_mfma_deep"
+        timer = self.eng.timed(group)
+        if timer.active:  # algorithmic bytes: input + residual read once, output written once (no partial sums any more)
+            st = self.conv_stats.setdefault(group, [0, 0])
+            st[0] += 2 * (x.numel() + out.numel() + (res.numel() if res is not None else 0))
+            st[1] += 2 * 9 * cin * cout * n * H * W
+        with timer:
+            _lib.check(self.lib.aliby_nn_conv3x3_deep_bf16(
+                self.h, _ptr(x), _ptr(self._pack(unit)), _ptr(out), _ptr(unit.scale), _ptr(sh), self._sps(sh),
+                _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
+                1 if in_up else 0, _stream_ptr()))
 
     def _launch_unit(self, x, unit, kslice, nslice, out, shift, bias, res, res_up, in_up, pooled):
         n, ctot, cout_tot = x.shape[0], x.shape[1], out.shape[1]

@@ -181,6 +181,25 @@ int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const uint16_t* cur
                        const int32_t* prev_tracked_dev, const int32_t* max_label_in_host, double threshold,
                        int32_t* cur_tracked_dev, int32_t* max_label_out_host, void* stream);
 
+/* The same unit for the deep levels of the network (128 / 256 channels at 56 x 56 and 28 x 28) as ONE launch: the whole
+ * K = 9 * CIN reduction is accumulated in fp32 registers (K loop over 64-channel slices inside the kernel, weights streamed
+ * from the packed array), instead of K/N-slice launches of aliby_nn_conv3x3_bf16 adding bf16 partial sums through HBM.
+ * Arguments as aliby_nn_conv3x3_bf16 (full tensors, no channel slices); wpk = aliby_nn_pack_conv3x3_bf16 over the full CIN.
+ * Supported: CIN in {64, 128, 256}, COUT a multiple of 128, W <= 56, (H + 1) * (W + 2) >= 226 + 2 * (W + 2) when the shift
+ * is per sample; anything else returns ALIBY_ERR_UNSUPPORTED (the caller then uses the slice launches).
+ * Replaces: cellpose `batchconv` / `batchconvstyle` at the deep levels of the network `model.eval` runs
+ * (segment/dispatch.py:208-215). */
+int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                               const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
+                               int N, int H, int W, int CIN, int COUT, int in_up, void* stream);
+/* Diagnostics for the deep kernel: stamps_dev [8 tiles][32] uint64 shader-clock stamps of wave 0 of workgroup 0 (0 tile start,
+ * 1 set-up done, then per K slice s: 2+4s after the first barrier, 3+4s prologue written, 4+4s after the second barrier,
+ * 5+4s MFMA loop done; 2+4S epilogue done).  NULL switches it off (the default). */
+int aliby_debug_conv_deep_trace(aliby_ctx* ctx, void* stamps_dev);
+/* max_pool2d(IN, 2, 2) on bf16 NHWC [N,H,W,C] -> [N,H/2,W/2,C] (cellpose `downsample.maxpool` between the levels whose
+ * last convolution runs on the deep kernel; elsewhere the pooled tensor is an epilogue of aliby_nn_conv3x3_bf16). */
+int aliby_nn_maxpool2_bf16(aliby_ctx* ctx, const void* in, void* out, int N, int H, int W, int C, void* stream);
+
 /* Diagnostics: when stamps_dev != NULL, wave 0 of workgroup 0 of every following conv3x3 launch (register-staged
  * variant) writes its shader-clock stamps at the phase boundaries of its first 16 tiles into stamps_dev[16][8]
  * (uint64: 0 tile start, 1 loads issued, 2 after barrier, 3 prologue done, 4 after barrier, 5 MFMA done,

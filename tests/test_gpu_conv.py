@@ -404,3 +404,105 @@ def test_conv_unit_rejects_unsupported_shapes(engine):
     with pytest.raises(Exception, match="unsupported"):
         _lib.check(engine.lib.aliby_nn_conv3x3_bf16(engine.ctx.handle, _ptr(x), _ptr(x), _ptr(x), _ptr(f), _ptr(f), 0, 0, 0, 0,
                                                     1, 8, 8, 16, 16, 0, 0, 0, 0, 0, 0, _stream_ptr()))
+
+
+# ------------------------------------------------------------------------------------------ the deep-level K-loop kernel
+DEEP = [(64, 128, False), (128, 128, False), (128, 256, False), (256, 256, False), (256, 128, True), (128, 128, True)]
+
+
+def _run_deep(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    n, cin = x.shape[0], x.shape[-1]
+    cout = w.shape[0]
+    wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), cout, w.shape[1], cin, _ptr(wpk), _stream_ptr()))
+    out = torch.full((n, H, W, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_conv3x3_deep_bf16(
+        engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1 if shift.ndim == 2 else 0,
+        _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
+        1 if in_up else 0, _stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("shape", [(3, 28, 28), (5, 56, 56), (2, 20, 36), (1, 12, 50), (9, 28, 28)])
+@pytest.mark.parametrize("cin,cout,in_up", DEEP)
+def test_deep_conv_exact_on_integer_data(engine, cin, cout, in_up, shape):
+    """aliby_nn_conv3x3_deep_bf16 (one launch, fp32 accumulation over the whole 9*CIN reduction) on data where every product and
+    sum is exact: any mistake in the flattened-position / tall-image / fragment logic is a wrong integer.  Images of several
+    sizes, batches that end inside a tile, per-sample shifts (a window spans two images), upsampled input and residual."""
+    import torch
+
+    g = torch.Generator().manual_seed(cin * 7 + cout + shape[1])
+    n, H, W = shape
+    ih, iw = (H // 2, W // 2) if in_up else (H, W)
+    x = torch.randint(-1, 3, (n, ih, iw, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand(cout, cin, 3, 3, generator=g) < 0.04)).float().cuda()
+    scale = torch.randint(1, 3, (cin,), generator=g).float().cuda()
+    shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
+    bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
+    res = torch.randint(-3, 4, (n, H // 2, W // 2, cout), generator=g).to(torch.bfloat16).cuda()
+    out = _run_deep(engine, x, w, scale, shift, bias, res, True, in_up, H, W)
+    ref = _reference(x, w, scale, shift, bias, res, True, in_up)
+    assert float(ref.abs().max()) <= 256
+    assert torch.equal(out.float(), ref), (out.float() - ref).abs().max()
+    # no residual, shared shift, no bias
+    out2 = _run_deep(engine, x, w, scale, shift[0].contiguous(), None, None, False, in_up, H, W)
+    assert torch.equal(out2.float(), _reference(x, w, scale, shift[0], None, None, False, in_up))
+
+
+def test_deep_conv_random_data_is_closer_to_fp32_than_the_sliced_launches(engine):
+    """Random data: the K-loop kernel rounds to bf16 once (|err| <= 2^-8 of the value + fp32 summation noise); the K-split
+    launches it replaces rounded their partial sums to bf16 three times for a 256-channel input."""
+    import torch
+
+    g = torch.Generator().manual_seed(5)
+    n, H, W, cin, cout = 4, 28, 28, 256, 256
+    x = torch.randn((n, H, W, cin), generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin**0.5)).float().cuda()
+    scale = (1 + 0.1 * torch.randn(cin, generator=g)).float().cuda()
+    shift = (0.1 * torch.randn((n, cin), generator=g)).float().cuda()
+    bias = torch.randn(cout, generator=g).float().cuda()
+    res = torch.randn((n, H, W, cout), generator=g).to(torch.bfloat16).cuda()
+    out = _run_deep(engine, x, w, scale, shift, bias, res, False, False, H, W).float()
+    ref = _reference(x, w, scale, shift, bias, res, False, False)
+    err = (out - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 2e-3).all())  # one bf16 rounding of the result + fp32 summation noise
+    rel_l2 = float((out - ref).norm() / ref.norm())
+    assert rel_l2 < 2.5e-3, rel_l2  # bf16 output rounding alone is ~1.6e-3 rms
+    # the slice launches: 4 K-slices x 2 N-slices chained through the bf16 output
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    sliced = torch.empty((n, H, W, cout), dtype=torch.bfloat16, device="cuda")
+    for n0 in range(0, cout, 128):
+        cur = res
+        for k0 in range(0, cin, 64):
+            wk = w[n0:n0 + 128, k0:k0 + 64].contiguous()
+            wpk = torch.empty(128 * 64 * 9, dtype=torch.bfloat16, device="cuda")
+            _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(wk), 128, 64, 64, _ptr(wpk), _stream_ptr()))
+            last = k0 + 64 == cin
+            _lib.check(engine.lib.aliby_nn_conv3x3_bf16(
+                engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(sliced), _ptr(scale[k0:k0 + 64].contiguous()), _ptr(shift[:, k0:k0 + 64].contiguous()), 1,
+                _ptr(bias[n0:n0 + 128].contiguous()) if last else 0, _ptr(cur), 0, n, H, W, 64, 128, 0, cin, k0, cout, n0, 0, _stream_ptr()))
+            cur = sliced
+    torch.cuda.synchronize()
+    rel_sliced = float((sliced.float() - ref).norm() / ref.norm())
+    print(f"rel-L2 vs fp32 reference: K-loop {rel_l2:.2e}, K/N-slice launches {rel_sliced:.2e}")
+    assert rel_l2 < rel_sliced
+
+
+def test_maxpool2_bf16(engine):
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    x = torch.randn((3, 12, 20, 128), generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+    out = torch.empty((3, 6, 10, 128), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_maxpool2_bf16(engine.ctx.handle, _ptr(x), _ptr(out), 3, 12, 20, 128, _stream_ptr()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.max_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(out.float(), ref)
