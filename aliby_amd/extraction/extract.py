@@ -165,6 +165,78 @@ def _split(tileid_instructions):
     return objects, instructions, full
 
 
+class InverseMapping(dict):
+    """new (sequential) label -> original label of one (tile, stack) plane: what skimage's relabel_sequential returns as its
+    third value, as far as the reference uses it (`.in_values`, `[label]`; extract.py:496-503, 628)."""
+
+    @property
+    def in_values(self):
+        return np.asarray(list(self.keys()), dtype=np.int64)
+
+    @property
+    def out_values(self):
+        return np.asarray(list(self.values()), dtype=np.int64)
+
+
+def relabel_planes(masks):
+    """Overlapping-mask stacks, one [S,Y,X] integer array per tile (BABY's layered masks) -> (relabelled planes uint16
+    [P,Y,X] with labels 1..K per plane in ascending order of the original labels, tile index of every plane,
+    {(tile, stack): InverseMapping}).  Host side: the stacks arrive as NumPy arrays and a trap tile is ~14 k pixels."""
+    planes, tile_of, inverse = [], [], {}
+    for tile_i, stack in enumerate(masks):
+        stack = np.asarray(stack)
+        if stack.ndim == 2:
+            stack = stack[None]
+        if stack.ndim != 3:
+            raise Exception(f"each tile's overlapping masks must be a [stack, Y, X] array, got shape {stack.shape}")
+        for stack_i, plane in enumerate(stack):
+            uniq = np.unique(plane)
+            uniq = uniq[uniq != 0]
+            if uniq.size and (uniq.min() < 0 or uniq.size >= 65535):
+                raise OverflowError(f"tile {tile_i}, stack {stack_i}: labels outside the uint16 range")
+            inverse[(tile_i, stack_i)] = InverseMapping({0: 0, **{k + 1: int(v) for k, v in enumerate(uniq)}})
+            planes.append(np.searchsorted(uniq, plane).astype(np.uint16) + (plane != 0).astype(np.uint16) if uniq.size
+                          else np.zeros(plane.shape, np.uint16))
+            tile_of.append(tile_i)
+    return planes, tile_of, inverse
+
+
+def _run_overlap(tileid_instructions, masks, pixels, cp_measure_kwargs):
+    """extract_tree(overlap=True): every (tile, stack) plane is one label image of the batched object table; the pixels of
+    a plane are its tile's.  Rows come out in (tile, stack, label) order, the order process_tree_masks_overlap enumerates."""
+    if not len(tileid_instructions):
+        return []
+    import torch
+
+    from aliby_amd.extraction.engine import FeatureEngine
+
+    eng = FeatureEngine()
+    planes_host, tile_of, inverse = relabel_planes(masks)
+    labels = _stack_masks([p for p in planes_host])
+    table = eng.object_table(labels)
+    planes = None
+    if pixels is not None:
+        px, dt = _device_pixels(pixels)
+        planes = (px.index_select(0, torch.as_tensor(tile_of, device=px.device)), dt)  # [P,C,Z,Y,X]: plane p sees its tile's pixels
+    instructions = list(dict.fromkeys(t[1] for t in tileid_instructions))
+    matrix_dev, blocks = families.evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs or {}, multi=False)
+    matrix = eng.to_host(matrix_dev)
+    stack_of, seen = [], {}
+    for p, t in enumerate(tile_of):
+        stack_of.append(seen.get(t, 0))
+        seen[t] = stack_of[-1] + 1
+    row_objects = [(tile_of[int(p)], stack_of[int(p)], int(l)) for p, l in zip(table.host["tile"], table.host["label"])]
+    row_of = {o: i for i, o in enumerate(row_objects)}
+    inst_index = {inst: k for k, inst in enumerate(instructions)}
+    try:
+        pairs = [(row_of[tuple(t[0])], inst_index[t[1]]) for t in tileid_instructions]
+    except KeyError as e:
+        raise IndexError(f"no object {e.args[0]} (tile, stack, label) in the overlapping masks") from None
+    res = DeviceResults(matrix, row_objects, instructions, blocks, pairs=pairs)
+    res.inverse_mappings = inverse
+    return res
+
+
 def _run(tileid_instructions, masks, pixels, cp_measure_kwargs, multi):
     if not len(tileid_instructions):
         return []
@@ -198,7 +270,8 @@ def extract_tree(tileid_instructions, masks, pixels, ncores=False, progress_bar=
                  cp_measure_kwargs=None):
     """Single-channel features for every (object, instruction) (extract.py:304-375)."""
     if overlap:
-        raise NotImplementedError("overlapping-mask extraction (extract.py:156-197) is SURVEY §8f-4")
+        # measure_mono_overlap (extract.py:156-197): object (tile, stack, label) of a [stack, Y, X] mask array per tile
+        return _run_overlap(tileid_instructions, masks, pixels, cp_measure_kwargs)
     return _run(tileid_instructions, masks, pixels, cp_measure_kwargs, multi=False)
 
 
@@ -222,8 +295,60 @@ def process_tree_masks(tree, masks, pixels, measure_fn, ncores=None, progress_ba
     return tileid_instructions, result
 
 
-def process_tree_masks_overlap(*args, **kwargs):
-    raise NotImplementedError("overlapping-mask extraction (extract.py:456-517) is SURVEY §8f-4, not built")
+def process_tree_masks_overlap(tree, masks, pixels, measure_fn, ncores=None, progress_bar=False, overlap=True,
+                               cp_measure_kwargs=None):
+    """Overlapping masks (BABY's layered output): `masks[tile]` is a [stack, Y, X] integer array whose planes hold objects
+    that may overlap ACROSS planes (extract.py:456-517).  Per (tile, stack) plane the labels are made sequential
+    (skimage `relabel_sequential`, ascending original label) and every (tile, stack, sequential label) is measured with every
+    instruction.  Returns (tileid_instructions, results) like the reference; `results.inverse_mappings` holds the
+    {(tile, stack): new label -> original label} maps that `format_extraction_overlap` needs as its third item.
+
+    One documented difference: the reference's `extract_tree(overlap=True)` builds its boolean masks from the UN-relabelled
+    stack (`transform_2d_to_3d(mask)`, extract.py:348) and indexes them with the relabelled id (`masks[tile][label - 1, stack]`,
+    extract.py:193), which is the same object only when a plane's labels are already 1..K; here the k-th label of the plane
+    (ascending) is object k whatever the original numbering — identical to the reference on sequential planes."""
+    if not isinstance(masks, list):
+        masks = [masks]
+    instructions = kv(flatten(tree))
+    _, _, inverse = relabel_planes(masks)
+    tile_stack_mask = [(tile_i, stack_i, int(mask_i)) for (tile_i, stack_i), inv in inverse.items()
+                       for mask_i in inv.in_values[inv.in_values > 0]]
+    tileid_instructions = tuple(product(tile_stack_mask, instructions))
+    extra = {}
+    if cp_measure_kwargs is not None:
+        extra["cp_measure_kwargs"] = cp_measure_kwargs
+    result = measure_fn(tileid_instructions, masks, pixels, ncores=ncores, progress_bar=progress_bar, **extra)
+    return tileid_instructions, result
+
+
+def format_extraction_overlap(instructions_result) -> pa.Table:
+    """(instructions, results, inverse_mappings) -> wide table keyed by (tile, ORIGINAL label) (extract.py:602-682): the
+    label column is `inverse_mappings[tile, stack][label]`, columns are sorted, `tile` / `label` come back as
+    `metadata_tile` / `metadata_label`."""
+    inverse_mappings = instructions_result[-1]
+    rows, metrics_seen = {}, set()
+    for inst, metrics in zip(*instructions_result[:2], strict=True):
+        tileid, stack_id, label = inst[0]
+        branch = "/".join(str(x) for x in inst[1])
+        original = inverse_mappings[tileid, stack_id][label]
+        row = rows.setdefault((tileid, original), {"tile": tileid, "label": original})
+        if isinstance(metrics, (int, float)):
+            row[f"{branch}/{inst[1][-1]}"] = metrics
+            metrics_seen.add(f"{branch}/{inst[1][-1]}")
+        elif isinstance(metrics, dict):
+            for k, values in metrics.items():
+                for value in values:
+                    row[f"{branch}/{k}"] = value
+                    metrics_seen.add(f"{branch}/{k}")
+        elif isinstance(metrics, list):
+            for value in metrics:
+                row[f"{branch}/{inst[1][-1]}"] = value
+                metrics_seen.add(f"{branch}/{inst[1][-1]}")
+    names = sorted(metrics_seen)
+    out = {"metadata_tile": [r["tile"] for r in rows.values()], "metadata_label": [r["label"] for r in rows.values()]}
+    for m in names:
+        out[m] = [r.get(m, None) for r in rows.values()]
+    return pa.Table.from_pydict(out)
 
 
 # --------------------------------------------------------------------------------------------

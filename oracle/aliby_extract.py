@@ -153,6 +153,40 @@ def process_tree_masks(tree, masks, pixels, measure_fn, cp_measure_kwargs=None, 
     return tileid_instructions, result
 
 
+def relabel_sequential(plane):
+    """skimage.segmentation.relabel_sequential(plane): (relabelled, {new: old}); ascending original labels -> 1..K."""
+    uniq = np.unique(plane)
+    uniq = uniq[uniq != 0]
+    fwd = {int(v): k + 1 for k, v in enumerate(uniq)}
+    out = np.zeros(plane.shape, np.int64)
+    for old, new in fwd.items():
+        out[plane == old] = new
+    return out, {0: 0, **{new: old for old, new in fwd.items()}}
+
+
+def process_tree_masks_overlap(tree, masks, pixels, cp_measure_kwargs=None):
+    """extract.py:456-517 + extract_tree(overlap=True) 304-359 + measure_mono_overlap 156-197, with the object of
+    (tile, stack, k) taken as the k-th label of the RELABELLED plane (see aliby_amd.extraction.extract: the shipped code
+    indexes the un-relabelled stack with relabelled ids).  Returns (tileid_instructions, results, inverse_mappings)."""
+    if not isinstance(masks, list):
+        masks = [masks]
+    instructions = kv(flatten(tree))
+    funs = load_cellfuns(cp_measure_kwargs)
+    tsm, inverse, relabelled = [], {}, {}
+    for tile_i, stack in enumerate(masks):
+        for stack_i, plane in enumerate(np.asarray(stack)):
+            rel, inv = relabel_sequential(plane)
+            relabelled[(tile_i, stack_i)] = rel
+            inverse[(tile_i, stack_i)] = inv
+            tsm.extend((tile_i, stack_i, k) for k in sorted(inv) if k > 0)
+    tileid_instructions = tuple(product(tsm, instructions))
+    result = []
+    for (tile_i, stack_i, k), (ch, red_z, metric) in tileid_instructions:
+        mask = relabelled[(tile_i, stack_i)] == k
+        result.append(measure(mask, pixels[tile_i, ch] if ch != "None" else None, REDUCTION_FUNS[red_z], funs[metric]))
+    return tileid_instructions, result, inverse
+
+
 def format_extraction_records(instructions_result):
     """Long records (tile, label, metric, value) exactly as format_extraction builds them
     (extract.py:534-572) — the pivot itself is product code and is tested against this."""

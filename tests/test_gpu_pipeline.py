@@ -342,3 +342,61 @@ def test_c_caller_runs_the_stager_without_python(tmp_path, engine):
     out = subprocess.run([str(build_c_demo(tmp_path))], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "tile0[0,0]=210 (expect 210)" in out.stdout and out.stdout.strip().endswith("ok")
+
+
+def test_overlapping_mask_extraction_matches_oracle(engine):
+    """§8f-4 second half: BABY-style layered masks — objects that overlap sit in different planes of a [stack, Y, X] array per
+    tile, labels arrive non-sequential (extract.py:456-517, 156-197, 602-682).  process_tree_masks_overlap + extract_tree
+    (overlap=True) against the oracle restatement; format_extraction_overlap restores the original labels."""
+    from aliby_amd.extraction.extract import extract_tree, format_extraction, format_extraction_overlap, process_tree_masks_overlap
+    from aliby_amd.pipe_core import _init_extract
+    from functools import partial
+    from oracle import aliby_extract as ox
+
+    rng = np.random.default_rng(3)
+    Y, X = 96, 117
+    yy, xx = np.mgrid[:Y, :X]
+
+    def disc(cy, cx, r):
+        return (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+
+    tile0 = np.zeros((2, Y, X), np.int32)
+    tile0[0][disc(30, 30, 12)] = 7      # overlaps label 12 of the other plane
+    tile0[0][disc(60, 80, 10)] = 3
+    tile0[1][disc(36, 38, 11)] = 12
+    tile0[1][disc(20, 95, 6)] = 40
+    tile1 = np.zeros((3, Y, X), np.int32)
+    tile1[0][disc(50, 50, 15)] = 2
+    tile1[2][disc(55, 58, 14)] = 5      # plane 1 is empty
+    masks = [tile0, tile1]
+    pixels = rng.integers(200, 4000, size=(2, 2, 3, Y, X)).astype(np.uint16)  # [F, C, Z, Y, X]
+    tree = {"None": {"None": ["sizeshape", "area"]}, 1: {"max": ["intensity", "mean"]}, 0: {"add": ["intensity"]}}
+
+    inst, res = process_tree_masks_overlap(tree, masks, pixels, partial(extract_tree, overlap=True))
+    inst_o, res_o, inv_o = ox.process_tree_masks_overlap(tree, masks, pixels)
+    assert inst == inst_o
+    objs = list(dict.fromkeys(t[0] for t in inst))
+    assert objs == [(0, 0, 1), (0, 0, 2), (0, 1, 1), (0, 1, 2), (1, 0, 1), (1, 2, 1)]
+    assert {k: dict(v) for k, v in res.inverse_mappings.items()} == inv_o
+    assert res.inverse_mappings[0, 0][2] == 7 and res.inverse_mappings[0, 1][2] == 40 and res.inverse_mappings[1, 2][1] == 5
+    assert len(res) == len(res_o) == len(inst)
+    for a, b in zip(res, res_o):
+        if isinstance(b, dict):
+            for k in b:
+                assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-8, equal_nan=True), k
+        else:
+            assert np.isclose(a, b, rtol=1e-4)
+    # the engine's pivot (get_profiles_from_state calls format_extraction): keyed by (tile, relabelled id)
+    t = format_extraction((inst, res)).to_pandas()
+    assert sorted(zip(t["tile"], t["label"])) == [(0, 1), (0, 2), (1, 1)]  # ids collide across planes, as in the reference
+    # the overlap-aware pivot: keyed by (tile, ORIGINAL label), one row per object
+    t2 = format_extraction_overlap((inst, res, res.inverse_mappings)).to_pandas()
+    assert list(zip(t2["metadata_tile"], t2["metadata_label"])) == [(0, 3), (0, 7), (0, 12), (0, 40), (1, 2), (1, 5)]
+    want_area = [int((tile0[0] == 3).sum()), int((tile0[0] == 7).sum()), int((tile0[1] == 12).sum()), int((tile0[1] == 40).sum()),
+                 int((tile1[0] == 2).sum()), int((tile1[2] == 5).sum())]
+    assert t2["None/None/sizeshape/Area"].tolist() == want_area and t2["None/None/area/area"].tolist() == want_area
+    # the step the BABY flavour's init_step builds (pipe_baby.py:79-80 -> pipe_core._init_extract(overlap=True))
+    step = _init_extract("extract_cells", {"tree": tree}, overlap=True)
+    inst2, res2 = step(masks=masks, pixels=pixels)
+    assert inst2 == inst and all(np.allclose(list(a.values())[0] if isinstance(a, dict) else a, list(b.values())[0] if isinstance(b, dict) else b,
+                                             equal_nan=True) for a, b in zip(res2, res))
