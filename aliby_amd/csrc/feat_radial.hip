@@ -32,6 +32,7 @@ struct RadialGeoArgs {
   size_t cap_cells;  // >= (max_h+2)*(max_w+2)
   unsigned char* gscratch;
   int bin_count;
+  double max_radius;  // > 0: unscaled rings of max_radius / bin_count pixels (+ overflow ring); <= 0: scaled rings
   unsigned char* binmap;  // [F,Y,X]
 };
 
@@ -148,7 +149,9 @@ __global__ __launch_bounds__(256) void k_radial_geometry(RadialGeoArgs a) {
       unsigned char code = 0;
       if (pth != 0xFFFFFFFFu) {
         const double dfrom = path_cost(pth), dedge = sqrt((double)dd);
-        const double nrm = dfrom / (dfrom + dedge + 0.001);
+        // scaled rings (the default): distance from the centre as a fraction of centre-to-edge; unscaled: in units of
+        // maximum_radius pixels, everything beyond it in the overflow ring `bin_count`
+        const double nrm = a.max_radius > 0 ? dfrom / a.max_radius : dfrom / (dfrom + dedge + 0.001);
         int bin = (int)(nrm * (double)a.bin_count);
         if (bin > a.bin_count) bin = a.bin_count;
         const int wedge = (r > ci ? 1 : 0) + (c > cj ? 2 : 0) + (abs(r - ci) > abs(c - cj) ? 4 : 0);
@@ -167,6 +170,7 @@ struct RadialStatArgs {
   int F, C, Y, X, channel;
   const aliby_object* tab;
   int n_obj, bin_count;
+  int nout;  // rings reported: bin_count (scaled) or bin_count + 1 (unscaled: the overflow ring too)
   double* out;
   int ld, col0;
 };
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void k_radial_stats(RadialStatArgs a) {
     const aliby_object o = a.tab[oi];
     double* out = a.out + (size_t)oi * a.ld + a.col0;
     if (o.area <= 0) {
-      for (int k = tid; k < 3 * nb; k += blockDim.x) out[k] = NAN;
+      for (int k = tid; k < 3 * a.nout; k += blockDim.x) out[k] = NAN;
       continue;
     }
     __syncthreads();
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void k_radial_stats(RadialStatArgs a) {
       atomicAdd(&wcnt[bin][wedge], 1);
     }
     __syncthreads();
-    if (tid < nb) {
+    if (tid < a.nout) {
       double T_ = 0, N_ = 0;
       for (int b = 0; b <= nb; ++b) { T_ += tot[b]; N_ += (double)cnt[b]; }
       const double fd = tot[tid] / T_;
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(256) void k_radial_stats(RadialStatArgs a) {
         cv = sqrt(var / (double)nw) / mean;
       }
       out[tid] = fd;
-      out[nb + tid] = fd / (fb + 2.220446049250313e-16);
-      out[2 * nb + tid] = cv;
+      out[a.nout + tid] = fd / (fb + 2.220446049250313e-16);
+      out[2 * a.nout + tid] = cv;
     }
     __syncthreads();
   }
@@ -239,6 +243,12 @@ extern "C" {
 int aliby_radial_geometry(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
                           const aliby_object* table_dev, int n_obj, int max_h, int max_w, int bin_count,
                           uint8_t* binmap_dev, void* stream) {
+  return aliby_radial_geometry_unscaled(ctx, labels, F, Y, X, table_dev, n_obj, max_h, max_w, bin_count, 0.0, binmap_dev, stream);
+}
+
+int aliby_radial_geometry_unscaled(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                                   const aliby_object* table_dev, int n_obj, int max_h, int max_w, int bin_count,
+                                   double maximum_radius, uint8_t* binmap_dev, void* stream) {
   ARG_CHECK(ctx != nullptr, "ctx is NULL");
   if (n_obj == 0) return ALIBY_OK;
   ARG_CHECK(labels && table_dev && binmap_dev, "NULL argument");
@@ -247,6 +257,7 @@ int aliby_radial_geometry(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, 
   ARG_CHECK(max_h + max_w < 16000, "object too large for 16-bit path counters");
   RadialGeoArgs a;
   a.labels = labels; a.F = F; a.Y = Y; a.X = X; a.tab = table_dev; a.n_obj = n_obj; a.bin_count = bin_count;
+  a.max_radius = maximum_radius;
   a.binmap = binmap_dev;
   a.cap_cells = ((size_t)(max_h + 2) * (max_w + 2) + 3) & ~(size_t)3;
   const size_t need = a.cap_cells * 8;
@@ -271,16 +282,26 @@ int aliby_features_radial_distribution(aliby_ctx* ctx, const uint16_t* labels, c
                                        const void* planes, int dtype, int F, int C, int Y, int X,
                                        int channel, const aliby_object* table_dev, int n_obj,
                                        int bin_count, double* out, int ld, int col0, void* stream) {
+  return aliby_features_radial_distribution_rings(ctx, labels, binmap_dev, planes, dtype, F, C, Y, X, channel, table_dev, n_obj,
+                                                  bin_count, bin_count, out, ld, col0, stream);
+}
+
+int aliby_features_radial_distribution_rings(aliby_ctx* ctx, const uint16_t* labels, const uint8_t* binmap_dev,
+                                             const void* planes, int dtype, int F, int C, int Y, int X,
+                                             int channel, const aliby_object* table_dev, int n_obj,
+                                             int bin_count, int rings_out, double* out, int ld, int col0, void* stream) {
   ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  ARG_CHECK(rings_out == bin_count || rings_out == bin_count + 1, "rings_out is bin_count (scaled) or bin_count + 1 (with the overflow ring)");
   if (n_obj == 0) return ALIBY_OK;
   ARG_CHECK(labels && binmap_dev && planes && table_dev && out, "NULL argument");
   ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
   ARG_CHECK(channel >= 0 && channel < C, "channel out of range");
   ARG_CHECK(bin_count >= 1 && bin_count < RD_MAXBINS, "1 <= bin_count < 16");
-  ARG_CHECK(col0 >= 0 && col0 + 3 * bin_count <= ld, "columns exceed row stride");
+  ARG_CHECK(col0 >= 0 && col0 + 3 * rings_out <= ld, "columns exceed row stride");
   RadialStatArgs a;
   a.labels = labels; a.binmap = binmap_dev; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X;
   a.channel = channel; a.tab = table_dev; a.n_obj = n_obj; a.bin_count = bin_count;
+  a.nout = rings_out;
   a.out = out; a.ld = ld; a.col0 = col0;
   hipStream_t s = as_stream(stream);
   if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_radial_stats<u16>), dim3(n_obj), dim3(256), 0, s, a);

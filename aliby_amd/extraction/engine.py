@@ -336,35 +336,39 @@ class FeatureEngine:
             )
         return 52
 
-    def radial_geometry(self, labels, table: ObjectTable, bin_count: int) -> torch.Tensor:
-        """Ring/wedge code map [F,Y,X] uint8, computed once per (object table, bin_count)."""
+    def radial_geometry(self, labels, table: ObjectTable, bin_count: int, maximum_radius: float | None = None) -> torch.Tensor:
+        """Ring/wedge code map [F,Y,X] uint8, computed once per (object table, bin_count, maximum_radius).
+        maximum_radius=None: scaled rings; a number: unscaled rings of maximum_radius / bin_count pixels + overflow ring."""
         cache = getattr(table, "_binmaps", None)
         if cache is None:
             cache = table._binmaps = {}
-        if bin_count in cache:
-            return cache[bin_count]
+        key = bin_count if maximum_radius is None else (bin_count, float(maximum_radius))
+        if key in cache:
+            return cache[key]
         F, Y, X = labels.shape
         binmap = torch.zeros((F, Y, X), dtype=torch.uint8, device=labels.device)
         with self.timed("radial_geometry"):
-            _lib.check(self.lib.aliby_radial_geometry(self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj,
-                                                      table.max_h, table.max_w, int(bin_count), _ptr(binmap), _stream_ptr()))
-        cache[bin_count] = binmap
+            _lib.check(self.lib.aliby_radial_geometry_unscaled(
+                self.ctx.handle, _ptr(labels), F, Y, X, _ptr(table.dev), table.n_obj, table.max_h, table.max_w, int(bin_count),
+                0.0 if maximum_radius is None else float(maximum_radius), _ptr(binmap), _stream_ptr()))
+        cache[key] = binmap
         return binmap
 
     def radial_distribution(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, bin_count=4,
                             scaled=True, maximum_radius=100):
-        if not scaled:
-            raise NotImplementedError("radial_distribution(scaled=False) is not built; cp_measure's default is scaled")
+        if not scaled and not maximum_radius > 0:
+            raise ValueError("radial_distribution(scaled=False) needs maximum_radius > 0")
         F, Cn, Y, X = planes.shape
-        binmap = self.radial_geometry(labels, table, bin_count)
+        binmap = self.radial_geometry(labels, table, bin_count, None if scaled else maximum_radius)
+        rings = bin_count if scaled else bin_count + 1
         with self.timed("radial_distribution"):
             _lib.check(
-                self.lib.aliby_features_radial_distribution(
+                self.lib.aliby_features_radial_distribution_rings(
                     self.ctx.handle, _ptr(labels), _ptr(binmap), _ptr(planes), dtype, F, Cn, Y, X, int(channel),
-                    _ptr(table.dev), table.n_obj, int(bin_count), _ptr(out), out.stride(0), col0, _stream_ptr(),
+                    _ptr(table.dev), table.n_obj, int(bin_count), rings, _ptr(out), out.stride(0), col0, _stream_ptr(),
                 )
             )
-        return 3 * bin_count
+        return 3 * rings
 
     CELL_COLUMNS = ("area", "centroid_x", "centroid_y", "conical_volume", "eccentricity", "spherical_volume", "volume",
                     "min_ax", "maj_ax", "mean", "median", "std", "total", "total_squared", "max2p5pc", "max5px_median",

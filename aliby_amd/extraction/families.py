@@ -130,7 +130,7 @@ def register_optional(eng_cls):
         MONO["texture"] = dict(names=lambda kw: feat.texture_names(kw.get("scale", 3), kw.get("gray_levels", 256)),
                                launch=_launch_texture, needs_pixels=True)
     if hasattr(eng_cls, "radial_distribution"):
-        MONO["radial_distribution"] = dict(names=lambda kw: feat.radial_distribution_names(kw.get("bin_count", 4)),
+        MONO["radial_distribution"] = dict(names=lambda kw: feat.radial_distribution_names(kw.get("bin_count", 4), kw.get("scaled", True)),
                                            launch=_launch_radial_distribution, needs_pixels=True)
 
 
@@ -277,8 +277,8 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
             cache.get(inst[1])
         if metric in ("zernike", "radial_zernikes") and table.n_obj:
             eng.mec(labels, table)
-        if metric == "radial_distribution" and table.n_obj and kw.get("scaled", True):
-            eng.radial_geometry(labels, table, kw.get("bin_count", 4))
+        if metric == "radial_distribution" and table.n_obj:
+            eng.radial_geometry(labels, table, kw.get("bin_count", 4), None if kw.get("scaled", True) else kw.get("maximum_radius", 100))
     fan.fork()
     done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
     copies, after = [], []

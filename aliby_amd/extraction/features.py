@@ -121,10 +121,13 @@ def texture_names(scale: int = 3, gray_levels: int = 256) -> list[str]:
     return [f"{h}_{scale}_{d:02d}_{gray_levels}" for d in range(4) for h in HARALICK]
 
 
-def radial_distribution_names(bin_count: int = 4) -> list[str]:
+def radial_distribution_names(bin_count: int = 4, scaled: bool = True) -> list[str]:
+    """scaled=False adds CellProfiler's overflow ring (everything beyond maximum_radius) as `<stat>_Overflow`."""
     out = []
     for stat in ("FracAtD", "MeanFrac", "RadialCV"):
         out += [f"RadialDistribution_{stat}_{b}of{bin_count}" for b in range(1, bin_count + 1)]
+        if not scaled:
+            out.append(f"RadialDistribution_{stat}_Overflow")
     return out
 
 
@@ -154,7 +157,7 @@ def family_names(family: str, **kw) -> list[str]:
     if family == "texture":
         return texture_names(kw.get("scale", 3), kw.get("gray_levels", 256))
     if family == "radial_distribution":
-        return radial_distribution_names(kw.get("bin_count", 4))
+        return radial_distribution_names(kw.get("bin_count", 4), kw.get("scaled", True))
     if family == "radial_zernikes":
         return radial_zernike_names()
     if family in COLOC:

@@ -343,6 +343,17 @@ int aliby_features_radial_distribution(aliby_ctx* ctx, const uint16_t* labels, c
                                        const void* planes, int dtype, int F, int C, int Y, int X,
                                        int channel, const aliby_object* table_dev, int n_obj,
                                        int bin_count, double* out, int ld, int col0, void* stream);
+/* The same with `scaled=False` (CellProfiler's unscaled bins): rings of maximum_radius / bin_count pixels of centre distance,
+ * everything beyond maximum_radius in an overflow ring.  aliby_radial_geometry_unscaled writes ring `bin_count` for those
+ * pixels; aliby_features_radial_distribution_rings with rings_out = bin_count + 1 reports it as a last column of each of
+ * FracAtD / MeanFrac / RadialCV (3 * rings_out columns; rings_out = bin_count is the scaled call above). */
+int aliby_radial_geometry_unscaled(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X,
+                                   const aliby_object* table_dev, int n_obj, int max_h, int max_w, int bin_count,
+                                   double maximum_radius, uint8_t* binmap_dev, void* stream);
+int aliby_features_radial_distribution_rings(aliby_ctx* ctx, const uint16_t* labels, const uint8_t* binmap_dev,
+                                             const void* planes, int dtype, int F, int C, int Y, int X,
+                                             int channel, const aliby_object* table_dev, int n_obj,
+                                             int bin_count, int rings_out, double* out, int ld, int col0, void* stream);
 
 /* ---- a15: the reference's in-repo per-cell metrics ------------------------ */
 /* extraction/core/functions/cell.py:18-303.  17 columns: area, centroid_x, centroid_y, conical_volume,

@@ -59,10 +59,12 @@ def propagate_from(mask, ci, cj):
     return dist
 
 
-def names(bin_count=4):
+def names(bin_count=4, scaled=True):
     out = []
     for stat in ("FracAtD", "MeanFrac", "RadialCV"):
         out += [f"RadialDistribution_{stat}_{b}of{bin_count}" for b in range(1, bin_count + 1)]
+        if not scaled:  # CellProfiler's overflow ring of the unscaled mode: everything beyond maximum_radius
+            out.append(f"RadialDistribution_{stat}_Overflow")
     return out
 
 
@@ -70,7 +72,7 @@ def get_radial_distribution(masks, pixels, scaled=True, bin_count=4, maximum_rad
     labels = np.asarray(masks)
     img = np.asarray(pixels).astype(np.float64)
     idx = _indices(labels)
-    res = {n: np.full(len(idx), np.nan) for n in names(bin_count)}
+    res = {n: np.full(len(idx), np.nan) for n in names(bin_count, scaled)}
     nb = bin_count + 1
     for k, lab in enumerate(idx):
         full = labels == lab
@@ -105,7 +107,7 @@ def get_radial_distribution(masks, pixels, scaled=True, bin_count=4, maximum_rad
         ii, jj = np.mgrid[0 : m.shape[0], 0 : m.shape[1]]
         wedge = (ii > ci).astype(int) + 2 * (jj > cj).astype(int) + 4 * (np.abs(ii - ci) > np.abs(jj - cj)).astype(int)
         n_out = bin_count if scaled else bin_count + 1
-        for b in range(bin_count):
+        for b in range(n_out):
             sel = good & (bins == b)
             vals = np.zeros(8)
             cts = np.zeros(8)
@@ -118,8 +120,8 @@ def get_radial_distribution(masks, pixels, scaled=True, bin_count=4, maximum_rad
                     cv = np.std(means) / np.mean(means)
             else:
                 cv = 0.0
-            res[f"RadialDistribution_FracAtD_{b + 1}of{bin_count}"][k] = frac_at_d[b]
-            res[f"RadialDistribution_MeanFrac_{b + 1}of{bin_count}"][k] = mean_frac[b]
-            res[f"RadialDistribution_RadialCV_{b + 1}of{bin_count}"][k] = cv
-        del n_out
+            tag = f"{b + 1}of{bin_count}" if b < bin_count else "Overflow"
+            res[f"RadialDistribution_FracAtD_{tag}"][k] = frac_at_d[b]
+            res[f"RadialDistribution_MeanFrac_{tag}"][k] = mean_frac[b]
+            res[f"RadialDistribution_RadialCV_{tag}"][k] = cv
     return res

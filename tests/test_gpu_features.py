@@ -251,6 +251,30 @@ def test_radial_distribution_matches_oracle(engine, objset):
             torch.cuda.synchronize()
             ref = rr.get_radial_distribution(labels, planes[ch], bin_count=bin_count)
             _compare(names, out.cpu().numpy(), ref)
+    # scaled=False (CellProfiler's unscaled bins): rings of maximum_radius / bin_count pixels + the overflow ring
+    for bin_count, maximum_radius in ((4, 10), (5, 40), (4, 3)):
+        names = feat.radial_distribution_names(bin_count, scaled=False)
+        assert names == rr.names(bin_count, scaled=False) and len(names) == 3 * (bin_count + 1) and names[bin_count].endswith("_Overflow")
+        out = engine.new_output(tab.n_obj, len(names))
+        assert engine.radial_distribution(dl, dp, dt, 0, tab, out, 0, bin_count=bin_count, scaled=False, maximum_radius=maximum_radius) == len(names)
+        torch.cuda.synchronize()
+        ref = rr.get_radial_distribution(labels, planes[0], bin_count=bin_count, scaled=False, maximum_radius=maximum_radius)
+        _compare(names, out.cpu().numpy(), ref)
+        got = out.cpu().numpy()
+        present = np.bincount(labels.ravel())[1:] > 0
+        assert np.allclose(got[present][:, : bin_count + 1].sum(1), 1.0)  # the rings + the overflow partition the intensity
+    # through the registry, with kwargs (cp_measure_kwargs -> loaders.py:71-73)
+    from aliby_amd.extraction.extract import extract_tree, process_tree_masks
+    from oracle import aliby_extract as ox
+
+    kw = {"radial_distribution": {"scaled": False, "maximum_radius": 8, "bin_count": 3}}
+    tree = {1: {"max": ["radial_distribution"]}}
+    inst, res = process_tree_masks(tree, labels, f["pixels"][None], extract_tree, cp_measure_kwargs=kw)
+    inst_o, res_o = ox.process_tree_masks(tree, labels, f["pixels"][None], ox.extract_tree, cp_measure_kwargs=kw, max_objects=6)
+    assert list(res[0]) == list(res_o[0]) and "RadialDistribution_MeanFrac_Overflow" in res[0]
+    for a, b in zip(res, res_o):
+        for k in b:
+            assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-9, equal_nan=True), k
 
 
 def test_stream_fanout_is_bit_identical_to_single_stream(engine, monkeypatch):
