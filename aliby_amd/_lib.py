@@ -111,6 +111,8 @@ _SIGNATURES = {
     "aliby_features_texture": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_radial_geometry": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "aliby_features_radial_distribution": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "aliby_features_cell_ratio": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "aliby_features_trap_background": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "aliby_radial_geometry_unscaled": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, C.c_double, _vp, _vp]),
     "aliby_features_radial_distribution_rings": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_cell": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),

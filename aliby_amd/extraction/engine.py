@@ -389,6 +389,25 @@ class FeatureEngine:
             )
         return out
 
+    def cell_ratio(self, labels, planes, dtype, ch0, ch1, table: ObjectTable) -> torch.Tensor:
+        """[n_obj] float64: cell.ratio of the reference (cell.py:268-279) for the channel pair (ch0, ch1) of planes [F,C,Y,X]."""
+        F, Cn, Y, X = planes.shape
+        out = torch.full((max(table.n_obj, 1),), float("nan"), dtype=torch.float64, device=labels.device)
+        with self.timed("cell_metrics"):
+            _lib.check(self.lib.aliby_features_cell_ratio(self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch0), int(ch1),
+                                                          _ptr(table.dev), table.n_obj, table.max_area, _ptr(out), _stream_ptr()))
+        return out[: table.n_obj]
+
+    def trap_background(self, labels, planes, dtype, channel) -> torch.Tensor:
+        """[F, 2] float64: (trap.imBackground, trap.background_max5) of every tile (trap.py:6-43): median / mean of the five
+        largest of the pixels of `channel` that lie under no mask."""
+        F, Cn, Y, X = planes.shape
+        out = torch.empty((F, 2), dtype=torch.float64, device=labels.device)
+        with self.timed("trap_background"):
+            _lib.check(self.lib.aliby_features_trap_background(self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel),
+                                                               _ptr(out), _stream_ptr()))
+        return out
+
     def rank_planes(self, labels, planes, dtype, table: ObjectTable, channels):
         """uint32 [F,C,Y,X] dense ranks + int32 [n_obj,C] maxima for `channels`, cached on the table per plane tensor."""
         F, Cn, Y, X = planes.shape

@@ -124,6 +124,15 @@ for _m in _CELL_PIXELS:
     MONO[_m] = dict(names=lambda kw: None, launch=_make_cell_launch(_m), needs_pixels=True, cell=True)
 
 
+def _launch_ratio(eng, labels, table, plane, dt, ch, out, col0, kw):
+    # cell.ratio needs a [Y, X, 2] image (cell.py:270); the extraction path hands every metric ONE z-reduced plane, so the
+    # reference returns NaN for every object here.  The two-channel form is FeatureEngine.cell_ratio / functions.ratio.
+    out[:, col0] = float("nan")
+
+
+MONO["ratio"] = dict(names=lambda kw: None, launch=_launch_ratio, needs_pixels=True)
+
+
 def register_optional(eng_cls):
     """Families whose kernels are built in later commits register themselves when the engine has them."""
     if hasattr(eng_cls, "texture"):

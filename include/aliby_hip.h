@@ -363,6 +363,17 @@ int aliby_features_cell(aliby_ctx* ctx, const uint16_t* labels, const void* plan
                         int Y, int X, int channel, const aliby_object* table_dev, int n_obj, int max_h,
                         int max_w, int max_area, double* out, int ld, int col0, void* stream);
 
+/* cell.ratio (src/extraction/core/functions/cell.py:268-279): out[n_obj] = median over the object of channel0 / channel1 (true
+ * division), NaN when any channel1 pixel of the object is 0 or the object is empty. */
+int aliby_features_cell_ratio(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C, int Y,
+                              int X, int channel0, int channel1, const aliby_object* table_dev, int n_obj, int max_area,
+                              double* out, void* stream);
+/* trap.imBackground / trap.background_max5 (src/extraction/core/functions/trap.py:6-43): per tile, over the pixels of
+ * `channel` under NO mask (labels == 0): out[f*2] = their median (numpy.median), out[f*2+1] = the mean of the five largest
+ * (of all of them when fewer); NaN for a tile without background. */
+int aliby_features_trap_background(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
+                                   int Y, int X, int channel, double* out, void* stream);
+
 /* ---- a14: cp_measure colocalisation -------------------------------------- */
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the

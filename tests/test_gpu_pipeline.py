@@ -400,3 +400,55 @@ def test_overlapping_mask_extraction_matches_oracle(engine):
     inst2, res2 = step(masks=masks, pixels=pixels)
     assert inst2 == inst and all(np.allclose(list(a.values())[0] if isinstance(a, dict) else a, list(b.values())[0] if isinstance(b, dict) else b,
                                              equal_nan=True) for a, b in zip(res2, res))
+
+
+def test_ratio_and_trap_functions_match_the_reference_module(engine):
+    """cell.ratio, trap.imBackground and trap.background_max5 on the GPU against values produced by importing the reference's
+    own modules (tests/golden/reference_leaves.json: the pinned part of the oracle), plus edge cases against the oracle."""
+    import json
+    from pathlib import Path
+
+    from aliby_amd.extraction import functions as fn
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+    from oracle import cell_metrics as cm
+
+    g = Path(__file__).parent / "golden"
+    ref = json.loads((g / "reference_leaves.json").read_text())
+    inputs = np.load(g / "inputs_c1_256.npz")
+    lab = inputs["nuclei"]
+    stack = np.stack([inputs["pixels"][0, 0], inputs["pixels"][1, 0]], -1).astype(float)
+    want = [float("nan") if v is None else float(v) for v in ref["cell_ratio"]]
+    got = [fn.ratio(lab == l, stack) for l in range(1, 6)]
+    assert np.allclose(got, want, rtol=1e-12, equal_nan=True)
+    masks3 = np.stack([lab == l for l in range(1, 4)], axis=2)
+    img = inputs["pixels"][0, 0]
+    assert fn.imBackground(masks3, img) == ref["trap"]["imBackground"]
+    assert fn.background_max5(masks3, img) == ref["trap"]["background_max5"]
+    # a 2-D plane (what the extraction tree hands over): NaN, as in the reference
+    assert np.isnan(fn.ratio(lab == 1, img))
+    # a zero in the denominator anywhere in the cell -> NaN; an even pixel count -> mean of the two middle ratios
+    s2 = stack.copy()
+    yy, xx = np.nonzero(lab == 2)
+    s2[yy[0], xx[0], 1] = 0
+    assert np.isnan(fn.ratio(lab == 2, s2)) and np.isnan(cm.ratio(lab == 2, s2))
+    # batched forms over a label stack, every object / tile at once
+    labels = to_device_u16(np.stack([lab, np.roll(lab, 5, 1)]))
+    planes, dt = to_device_planes(np.stack([inputs["pixels"][:2, 0], inputs["pixels"][:2, 0]]))
+    tab = engine.object_table(labels)
+    r = engine.cell_ratio(labels, planes, dt, 0, 1, tab).cpu().numpy()
+    n = int(lab.max())
+    for l in (1, 3, n):
+        assert np.isclose(r[l - 1], cm.ratio(lab == l, stack), rtol=1e-12, equal_nan=True)
+    bg = engine.trap_background(labels, planes, dt, 1).cpu().numpy()
+    for f, lf in enumerate((lab, np.roll(lab, 5, 1))):
+        m = (lf > 0)[..., None]
+        assert bg[f, 0] == cm.imBackground(m, inputs["pixels"][1, 0]) and bg[f, 1] == cm.background_max5(m, inputs["pixels"][1, 0])
+    # float pixels, no masks at all, a fully covered tile
+    fimg = (inputs["pixels"][0, 0] / 65535.0).astype(np.float32)
+    assert np.isclose(fn.imBackground(np.zeros((0,)), fimg), np.median(fimg)) and np.isclose(fn.background_max5([], fimg), np.sort(fimg.ravel())[-5:].mean())
+    assert np.isnan(fn.imBackground(np.ones(img.shape + (1,), bool), img))
+    # "ratio" through the feature tree: a NaN column (the reference's behaviour on 2-D planes)
+    from aliby_amd.extraction.extract import extract_tree, process_tree_masks
+
+    inst, res = process_tree_masks({0: {"max": ["ratio", "mean"]}}, lab, inputs["pixels"][None, :, None][:, :, :, 0] if False else inputs["pixels"][None], extract_tree)
+    assert np.isnan(res[0]) and np.isfinite(res[1])
