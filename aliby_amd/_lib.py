@@ -113,6 +113,9 @@ _SIGNATURES = {
     "aliby_features_radial_distribution": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_cell_ratio": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "aliby_features_trap_background": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "aliby_granularity_workspace_bytes": (_sz, [_i, _i, _i, _i, C.c_double, C.c_double]),
+    "aliby_features_granularity": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, C.c_double, C.c_double, _i, _i, _i,
+                                        _vp, _sz, _vp, _i, _i, _vp]),
     "aliby_radial_geometry_unscaled": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, C.c_double, _vp, _vp]),
     "aliby_features_radial_distribution_rings": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_cell": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),

@@ -370,6 +370,29 @@ class FeatureEngine:
             )
         return 3 * rings
 
+    def granularity(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, subsample_size=0.25,
+                    image_sample_size=0.25, element_size=10, granular_spectrum_length=16, image_mask="frame", mask_order=1):
+        """cp_measure "granularity" (CellProfiler MeasureGranularity) of `channel` for every object: Granularity_1..L into
+        out[:, col0:col0+L].  image_mask: "frame" (CellProfiler's default: no image mask) or "objects" (labels > 0, sampled
+        with spline order `mask_order`; only the bilinear order 1 is built).  PARITY UNPINNED — oracle/granularity_restated.py."""
+        if image_mask not in ("frame", "objects"):
+            raise ValueError(f"image_mask must be 'frame' or 'objects', got {image_mask!r}")
+        if image_mask == "objects" and int(mask_order) != 1:
+            raise NotImplementedError("granularity(image_mask='objects') is built for mask_order=1 (bilinear) only")
+        F, Cn, Y, X = planes.shape
+        L = int(granular_spectrum_length)
+        need = int(self.lib.aliby_granularity_workspace_bytes(F, Y, X, table.n_obj, float(subsample_size), float(image_sample_size)))
+        work = torch.empty((need + 7) // 8, dtype=torch.float64, device=labels.device)
+        with self.timed("granularity"):
+            _lib.check(
+                self.lib.aliby_features_granularity(
+                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel), _ptr(table.dev), table.n_obj,
+                    float(subsample_size), float(image_sample_size), int(element_size), L, 1 if image_mask == "objects" else 0,
+                    _ptr(work), work.numel() * 8, _ptr(out), out.stride(0) if table.n_obj else max(L + col0, 1), col0, _stream_ptr(),
+                )
+            )
+        return L
+
     CELL_COLUMNS = ("area", "centroid_x", "centroid_y", "conical_volume", "eccentricity", "spherical_volume", "volume",
                     "min_ax", "maj_ax", "mean", "median", "std", "total", "total_squared", "max2p5pc", "max5px_median",
                     "moment_of_inertia")

@@ -87,6 +87,17 @@ def _launch_radial_distribution(eng, labels, table, plane, dt, ch, out, col0, kw
                             scaled=kw.get("scaled", True), maximum_radius=kw.get("maximum_radius", 100))
 
 
+def _launch_granularity(eng, labels, table, plane, dt, ch, out, col0, kw, **_):
+    if kw.get("image_mask", "frame") != "frame":
+        # the reference measures one object at a time on a single-object label image (extract.py:147-153): with the objects as
+        # the image mask, every object would get its own background and spectrum images.  Not built.
+        raise NotImplementedError("granularity(image_mask='objects') through the extraction tree is not built: the batched "
+                                  "kernels share one image-level spectrum per tile (image_mask='frame', CellProfiler's default)")
+    eng.granularity(labels, plane, dt, ch, table, out, col0, **{k: kw[k] for k in _GRANULARITY_KWARGS if k in kw})
+
+
+_GRANULARITY_KWARGS = ("subsample_size", "image_sample_size", "element_size", "granular_spectrum_length", "image_mask", "mask_order")
+
 # name -> {names(kw) -> list[str] | None (scalar), launch, needs_pixels}
 MONO = {
     "intensity": dict(names=lambda kw: feat.intensity_names(kw.get("edge_measurements", True)),
@@ -138,6 +149,11 @@ def register_optional(eng_cls):
     if hasattr(eng_cls, "texture"):
         MONO["texture"] = dict(names=lambda kw: feat.texture_names(kw.get("scale", 3), kw.get("gray_levels", 256)),
                                launch=_launch_texture, needs_pixels=True)
+    if hasattr(eng_cls, "granularity"):
+        # `cell` = run on the main stream after the fan-out has joined: the call iterates to a fixed point and waits on its
+        # stream in between
+        MONO["granularity"] = dict(names=lambda kw: feat.granularity_names(kw.get("granular_spectrum_length", 16)),
+                                   launch=_launch_granularity, needs_pixels=True, cell=True)
     if hasattr(eng_cls, "radial_distribution"):
         MONO["radial_distribution"] = dict(names=lambda kw: feat.radial_distribution_names(kw.get("bin_count", 4), kw.get("scaled", True)),
                                            launch=_launch_radial_distribution, needs_pixels=True)
@@ -211,11 +227,6 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
         kw = dict(cp_measure_kwargs.get(metric, {}))
         reg = MULTI if (multi and inst[1] == "None") else MONO
         if metric not in reg:
-            if metric == "granularity":
-                raise NotImplementedError(
-                    "cp_measure's 'granularity' (not in the builder's default feature list, pipe_builder.py:49-56) is not "
-                    "built: see DESIGN.md §7"
-                )
             raise KeyError(metric)
         names = reg[metric]["names"](kw)
         blocks.append((col, names))

@@ -131,6 +131,10 @@ def radial_distribution_names(bin_count: int = 4, scaled: bool = True) -> list[s
     return out
 
 
+def granularity_names(granular_spectrum_length: int = 16) -> list[str]:
+    return [f"Granularity_{i}" for i in range(1, int(granular_spectrum_length) + 1)]
+
+
 def radial_zernike_names() -> list[str]:
     out = [f"RadialDistribution_ZernikeMagnitude_{n}_{m}" for n, m in zernike_indexes()]
     out += [f"RadialDistribution_ZernikePhase_{n}_{m}" for n, m in zernike_indexes()]

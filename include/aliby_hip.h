@@ -374,6 +374,22 @@ int aliby_features_cell_ratio(aliby_ctx* ctx, const uint16_t* labels, const void
 int aliby_features_trap_background(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C,
                                    int Y, int X, int channel, double* out, void* stream);
 
+/* ---- a13 (widening): cp_measure "granularity" ------------------------------ */
+/* Bound like every core measurement at src/extraction/core/functions/loaders.py:71-73 (fun(mask, pixels) -> dict of
+ * Granularity_1..L); not in the builder's default list (pipe_builder.py:49-56).  CellProfiler's MeasureGranularity: frame
+ * subsampled by subsample_size (bilinear), background (erode + dilate with disk(element_size) on a further
+ * image_sample_size subsample) removed, then spectrum_length rounds of erode-by-disk(1) + reconstruction-by-dilation;
+ * out[obj, col0 + i - 1] = (mean_{i-1} - mean_i) * 100 / max(mean_0, eps) over the object's pixels, mean_0 on the
+ * original pixels.  image_mask_objects = 0: the image mask is the frame (CellProfiler's default); 1: labels > 0, sampled
+ * bilinearly.  The image-level part runs once per (tile, channel), float64.  `workspace` is device memory of at least
+ * aliby_granularity_workspace_bytes(); the call synchronises `stream` while it iterates the reconstruction to its fixed
+ * point.  PARITY UNPINNED (oracle/granularity_restated.py; cp_measure is not available offline). */
+size_t aliby_granularity_workspace_bytes(int F, int Y, int X, int n_obj, double subsample_size, double image_sample_size);
+int aliby_features_granularity(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C, int Y,
+                               int X, int channel, const aliby_object* table_dev, int n_obj, double subsample_size,
+                               double image_sample_size, int element_size, int spectrum_length, int image_mask_objects,
+                               void* workspace, size_t workspace_bytes, double* out, int ld, int col0, void* stream);
+
 /* ---- a14: cp_measure colocalisation -------------------------------------- */
 /* Call site wrap_cp_corr_features (loaders.py:153-167): fun(pixels1, pixels2, mask); metric list
  * pipe_builder.py:37.  One launch evaluates any subset of {pearson, manders_fold, rwc, costes} for the

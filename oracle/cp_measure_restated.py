@@ -425,6 +425,7 @@ def get_feret(masks, pixels=None):
 
 def get_core_measurements():
     """cp_measure.bulk.get_core_measurements() restated: name -> f(masks, pixels, **kw)."""
+    from oracle.granularity_restated import get_granularity
     from oracle.radial_restated import get_radial_distribution
     from oracle.texture_restated import get_texture
     from oracle.zernike_restated import get_radial_zernikes, get_zernike
@@ -437,6 +438,7 @@ def get_core_measurements():
         "zernike": get_zernike,
         "feret": get_feret,
         "texture": get_texture,
+        "granularity": get_granularity,
     }
 
 

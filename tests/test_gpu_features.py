@@ -303,3 +303,80 @@ def test_stream_fanout_is_bit_identical_to_single_stream(engine, monkeypatch):
     for x, y in zip(results["1"], results["4"]):
         assert x.shape == y.shape and x.shape[0] == table.n_obj
         assert np.array_equal(x, y, equal_nan=True)
+
+
+def test_granularity_matches_oracle(engine):
+    """cp_measure "granularity" (CellProfiler MeasureGranularity).  PARITY UNPINNED as a whole: cp_measure is not available
+    offline, the oracle (oracle/granularity_restated.py) restates CellProfiler's published algorithm and only its primitives
+    are pinned (scikit-image 0.18.3 fixture, tests/test_oracle_golden.py).  float64 on both sides, rtol 1e-4 as north_star."""
+    import torch
+    from oracle import granularity_restated as gr
+    from aliby_amd.extraction import features as feat
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+
+    cases = [
+        ((256, 256), dict()),                                             # CellProfiler's defaults
+        ((250, 301), dict()),                                             # shapes that are not multiples of the subsampling
+        ((200, 232), dict(subsample_size=0.5, image_sample_size=0.5, element_size=4, granular_spectrum_length=6)),
+        ((96, 120), dict(subsample_size=1.0, image_sample_size=1.0, element_size=3, granular_spectrum_length=5)),
+        ((180, 180), dict(subsample_size=0.5, image_sample_size=1.0, element_size=5, granular_spectrum_length=4)),
+    ]
+    for k, (shape, kw) in enumerate(cases):
+        fovs = [synth.make_fov(1, 40 + 2 * k + i, shape=shape, n_target=14) for i in range(2)]
+        labels = np.stack([f["cells"] for f in fovs])
+        labels[1, 0:9, 10:30] = labels[1].max() + 1  # an object on the border
+        planes = np.stack([f["pixels"][:, 0] for f in fovs])  # [F, C, Y, X] uint16
+        dl = to_device_u16(labels)
+        dp, dt = to_device_planes(planes)
+        tab = engine.object_table(dl)
+        L = kw.get("granular_spectrum_length", 16)
+        names = feat.granularity_names(L)
+        assert names == gr.names(L)
+        for ch in range(planes.shape[1]):
+            out = engine.new_output(tab.n_obj, L + 2)
+            out.fill_(-7.0)
+            assert engine.granularity(dl, dp, dt, ch, tab, out, 1, **kw) == L
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            assert (got[:, 0] == -7.0).all() and (got[:, -1] == -7.0).all()  # only its own columns are written
+            row = 0
+            for f in range(len(fovs)):
+                ref = gr.get_granularity(labels[f], planes[f, ch], **kw)
+                n = int(labels[f].max())
+                _compare(names, got[row : row + n, 1 : 1 + L], ref)
+                row += n
+            assert row == tab.n_obj
+    # float32 pixels, and the objects-as-image-mask variant of the kernel (mask = every object of the tile, bilinear sampling)
+    f = synth.make_fov(1, 77, shape=(240, 240), n_target=16)
+    labels = f["cells"][None]
+    planes = (f["pixels"][:, 0].astype(np.float32) / 65535.0)[None]
+    dl = to_device_u16(labels)
+    dp, dt = to_device_planes(planes)
+    tab = engine.object_table(dl)
+    for kw in (dict(), dict(image_mask="objects", mask_order=1), dict(image_mask="objects", mask_order=1, subsample_size=0.5, image_sample_size=0.5, element_size=3, granular_spectrum_length=5)):
+        L = kw.get("granular_spectrum_length", 16)
+        out = engine.new_output(tab.n_obj, L)
+        engine.granularity(dl, dp, dt, 0, tab, out, 0, **kw)
+        torch.cuda.synchronize()
+        _compare(feat.granularity_names(L), out.cpu().numpy(), gr.get_granularity(labels[0], planes[0, 0], **kw))
+    with pytest.raises(NotImplementedError):
+        engine.granularity(dl, dp, dt, 0, tab, out, 0, image_mask="objects", mask_order=3)
+    # through the registry with kwargs, as the reference binds them (loaders.py:71-73), against the oracle's per-object loop
+    from aliby_amd.extraction.extract import extract_tree, process_tree_masks
+    from oracle import aliby_extract as ox
+
+    f = synth.make_fov(2, 78, shape=(128, 128), n_target=6)
+    kw = {"granularity": {"granular_spectrum_length": 4, "element_size": 4}}
+    tree = {0: {"max": ["granularity"]}, 1: {"max": ["granularity", "mean"]}}
+    inst, res = process_tree_masks(tree, f["cells"], f["pixels"][None], extract_tree, cp_measure_kwargs=kw)
+    inst_o, res_o = ox.process_tree_masks(tree, f["cells"], f["pixels"][None], ox.extract_tree, cp_measure_kwargs=kw)
+    assert [tuple(i) for i in inst] == [tuple(i) for i in inst_o] and len(res) == len(res_o)
+    for a, b in zip(res, res_o):
+        if isinstance(b, dict):
+            assert list(a) == list(b)
+            for k2 in b:
+                assert np.allclose(a[k2], b[k2], rtol=1e-4, atol=1e-9, equal_nan=True), k2
+        else:
+            assert np.allclose(a, b, rtol=1e-4, atol=1e-9, equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        process_tree_masks(tree, f["cells"], f["pixels"][None], extract_tree, cp_measure_kwargs={"granularity": {"image_mask": "objects"}})
