@@ -139,20 +139,99 @@ DEFINE_BLOCK_REDUCE(block_max_f64, double, wave_max, -INFINITY, fmax(r, o))
 DEFINE_BLOCK_REDUCE(block_max_i32, int, wave_max, INT_MIN, max(r, o))
 DEFINE_BLOCK_REDUCE(block_min_i32, int, wave_min, INT_MAX, min(r, o))
 
-// Ascending bitonic sort of `n2` (power of two) floats; works on LDS or global
-// scratch.  All threads of the block must call it.
+__device__ __forceinline__ float sort_lo(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float sort_hi(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double sort_lo(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double sort_hi(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ unsigned int sort_lo(unsigned int a, unsigned int b) { return min(a, b); }
+__device__ __forceinline__ unsigned int sort_hi(unsigned int a, unsigned int b) { return max(a, b); }
+__device__ __forceinline__ int sort_lo(int a, int b) { return min(a, b); }
+__device__ __forceinline__ int sort_hi(int a, int b) { return max(a, b); }
+
+// The cross-lane half of a bitonic stage (partner distance j < 64) for R register-resident elements per lane: element
+// i = 64 r + lane meets lane ^ j of the same register.  `k` is the run length of the merge the stage belongs to.
+template <typename T, int R>
+__device__ __forceinline__ void wave_sort_lanes(T (&v)[R], int k, int lane) {
+  for (int j = (k < 64 ? k : 64) >> 1; j > 0; j >>= 1) {
+    const bool lower = (lane & j) == 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const T o = __shfl_xor(v[r], j, WAVE);
+      const bool up = (((r << 6) | lane) & k) == 0;
+      v[r] = (lower == up) ? sort_lo(v[r], o) : sort_hi(v[r], o);
+    }
+  }
+}
+
+// Bitonic sort of 64 R elements by ONE wave with the elements in registers (a[64 r + lane] <-> v[r]): partner distances
+// below 64 are lane shuffles, distances of 64 and more are compare-exchanges between a lane's own registers.  About a fifth
+// of the instructions of the LDS loop below, which is what bounds the one-wave-per-object kernels (16 lanes per SIMD: four
+// cycles per wave instruction).  No NaNs expected (min / max instead of compare-and-swap).
+template <typename T, int R>
+__device__ __forceinline__ void wave_bitonic_sort_regs(T* a) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  T v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[r] = a[(r << 6) + lane];
+  for (int k = 2; k <= 64; k <<= 1) wave_sort_lanes<T, R>(v, k, lane);
+#pragma unroll
+  for (int kr = 2; kr <= R; kr <<= 1) {  // merges of run length k = 64 kr
+#pragma unroll
+    for (int jr = kr >> 1; jr > 0; jr >>= 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r & jr) continue;
+        const T x = v[r], y = v[r | jr];
+        const bool up = (r & kr) == 0;  // compile-time: bit k of i = 64 r + lane is a bit of r
+        v[r] = up ? sort_lo(x, y) : sort_hi(x, y);
+        v[r | jr] = up ? sort_hi(x, y) : sort_lo(x, y);
+      }
+    }
+    wave_sort_lanes<T, R>(v, kr << 6, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[(r << 6) + lane] = v[r];
+}
+
+// Ascending bitonic sort of `n2` (power of two) elements; works on LDS or global scratch.  All threads of the block must
+// call it.  A single-wave workgroup sorts up to 1024 elements in registers (wave_bitonic_sort_regs).
 template <typename T>
 __device__ __forceinline__ void block_bitonic_sort(T* a, int n2) {
+  if (blockDim.x <= WAVE && n2 <= 1024) {
+    __syncthreads();
+    if (n2 > 64) {
+      switch (n2 >> 6) {
+        case 2: wave_bitonic_sort_regs<T, 2>(a); break;
+        case 4: wave_bitonic_sort_regs<T, 4>(a); break;
+        case 8: wave_bitonic_sort_regs<T, 8>(a); break;
+        default: wave_bitonic_sort_regs<T, 16>(a); break;
+      }
+    } else {
+      // fewer than a wave's worth: pad in registers
+      const int lane = threadIdx.x & (WAVE - 1);
+      T v[1];
+      T keep = a[lane < n2 ? lane : 0];
+      // lanes >= n2 must hold something that sorts to the end: the largest element present
+      T big = keep;
+#pragma unroll
+      for (int o = WAVE / 2; o > 0; o >>= 1) big = sort_hi(big, __shfl_xor(big, o, WAVE));
+      v[0] = lane < n2 ? keep : big;
+      for (int k = 2; k <= 64; k <<= 1) wave_sort_lanes<T, 1>(v, k, lane);
+      if (lane < n2) a[lane] = v[0];
+    }
+    __syncthreads();
+    return;
+  }
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
-      for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-        int p = i ^ j;
-        if (p > i) {
-          T x = a[i], y = a[p];
-          bool up = ((i & k) == 0);
-          if ((x > y) == up) { a[i] = y; a[p] = x; }
-        }
+      // one compare-exchange per thread and iteration: pair t of the stage is (i, i | j) with bit j of i clear
+      for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        T x = a[i], y = a[p];
+        const bool up = ((i & k) == 0);
+        if ((x > y) == up) { a[i] = y; a[p] = x; }
       }
     }
   }

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void k_intensity(IntensityArgs a) {
   __shared__ int s_cnt;
   __shared__ double s_res[5];  // lq, med, uq, mad(k), mad(k+1)
 
-  float* vals = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * a.cap) : lds_vals;
+  float* vals = GLOBAL ? (a.gscratch + (size_t)blockIdx.x * (a.cap + a.cap / 32 + 1)) : lds_vals;
+  unsigned int* eflag = reinterpret_cast<unsigned int*>(vals + a.cap);  // edge bit of the staged value at the same position
   const int tid = threadIdx.x;
   const size_t plane = (size_t)a.Y * a.X;
 
@@ -62,41 +63,78 @@ __global__ __launch_bounds__(256) void k_intensity(IntensityArgs a) {
     const u16 L = (u16)o.label;
 
     if (tid == 0) s_cnt = 0;
+    if (a.edge)
+      for (int i = tid; i < (a.cap + 31) / 32; i += blockDim.x) eflag[i] = 0u;
     __syncthreads();
 
     // ---- pass 1: accumulate + stage values --------------------------------
+    // The bbox walk is latency-bound (one wave per ~400-pixel object): every load of a batch of GU pixels — the label, the
+    // pixel and the four neighbour labels of the edge test — is issued before the first is used, so a lane waits for HBM / L2
+    // once per batch instead of up to six times per pixel.  Addresses inside the (clamped) bbox are always valid.
     int n = 0, ne = 0;
     double sv = 0, sxv = 0, syv = 0, sve = 0;
     long long sx = 0, sy = 0;
     float vmin = INFINITY, vmax = -INFINITY, emin = INFINITY, emax = -INFINITY;
     int amax = -1;  // raveled index of the max (ties -> largest index)
-    for (int i = tid; i < npix; i += blockDim.x) {
-      const int yy = o.y0 + i / w, xx = o.x0 + i % w;
-      const size_t idx = (size_t)yy * a.X + xx;
-      if (lab[idx] != L) continue;
-      const float v = px_load<T>(px, idx);
-      ++n;
-      sv += (double)v;
-      sx += xx;
-      sy += yy;
-      sxv += (double)xx * (double)v;
-      syv += (double)yy * (double)v;
-      vmin = fminf(vmin, v);
-      if (v > vmax || (v == vmax && (int)idx > amax)) { vmax = v; amax = (int)idx; }
-      const int pos = atomicAdd(&s_cnt, 1);
-      vals[pos] = v;
-      if (a.edge) {
-        // inner boundary, 4-neighbourhood, image border replicated (skimage grey
-        // erosion/dilation default mode='reflect')
-        const int yu = max(yy - 1, 0), yd = min(yy + 1, a.Y - 1);
-        const int xl = max(xx - 1, 0), xr = min(xx + 1, a.X - 1);
-        const bool e = lab[(size_t)yu * a.X + xx] != L || lab[(size_t)yd * a.X + xx] != L ||
-                       lab[(size_t)yy * a.X + xl] != L || lab[(size_t)yy * a.X + xr] != L;
-        if (e) {
-          ++ne;
-          sve += (double)v;
-          emin = fminf(emin, v);
-          emax = fmaxf(emax, v);
+    constexpr int GU = 4;
+    const bool single = blockDim.x <= WAVE;  // (then the staging order, and with it every sum below, is fixed)
+    int wbase = 0;
+    for (int i0 = tid; i0 < npix; i0 += GU * blockDim.x) {
+      int idx[GU];
+      u16 lb[GU], nb[GU][4];
+      float vv[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const bool in = i < npix;
+        const int ii = in ? i : 0;
+        const int yy = o.y0 + ii / w, xx = o.x0 + ii % w;
+        idx[u] = yy * a.X + xx;
+        lb[u] = lab[idx[u]];
+        if (!in) lb[u] = (u16)(L ^ 1);  // anything but L
+        vv[u] = px_load<T>(px, (size_t)idx[u]);
+        if (a.edge) {
+          // inner boundary, 4-neighbourhood, image border replicated (skimage grey erosion/dilation default mode='reflect')
+          const int yu = max(yy - 1, 0), yd = min(yy + 1, a.Y - 1);
+          const int xl = max(xx - 1, 0), xr = min(xx + 1, a.X - 1);
+          nb[u][0] = lab[(size_t)yu * a.X + xx];
+          nb[u][1] = lab[(size_t)yd * a.X + xx];
+          nb[u][2] = lab[(size_t)yy * a.X + xl];
+          nb[u][3] = lab[(size_t)yy * a.X + xr];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const bool hit = lb[u] == L;
+        // slot of the staged value: a single-wave workgroup compacts by ballot (lane order: deterministic, no atomics)
+        int pos = 0;
+        if (single) {
+          const unsigned long long m = __ballot(hit);
+          pos = wbase + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+          wbase += __popcll(m);
+        }
+        if (!hit) continue;
+        if (!single) pos = atomicAdd(&s_cnt, 1);
+        const float v = vv[u];
+        const int yy = idx[u] / a.X, xx = idx[u] - yy * a.X;
+        ++n;
+        sv += (double)v;
+        sx += xx;
+        sy += yy;
+        sxv += (double)xx * (double)v;
+        syv += (double)yy * (double)v;
+        vmin = fminf(vmin, v);
+        if (v > vmax || (v == vmax && idx[u] > amax)) { vmax = v; amax = idx[u]; }
+        vals[pos] = v;
+        if (a.edge) {
+          const bool e = nb[u][0] != L || nb[u][1] != L || nb[u][2] != L || nb[u][3] != L;
+          if (e) {
+            ++ne;
+            sve += (double)v;
+            emin = fminf(emin, v);
+            emax = fmaxf(emax, v);
+            if (single) atomicOr(&eflag[pos >> 5], 1u << (pos & 31));
+          }
         }
       }
     }
@@ -123,6 +161,36 @@ __global__ __launch_bounds__(256) void k_intensity(IntensityArgs a) {
       mean_e = SVE / (double)NE;
     }
 
+    // ---- edge second moment -----------------------------------------------------------------------------------
+    // single wave: over the staged (still unsorted) values whose edge bit is set; several waves stage in atomic order, which
+    // varies from run to run, so they walk the bbox again with a fixed pixel -> thread assignment
+    double SSE = 0;
+    if (a.edge) {
+      double sse = 0;
+      if (single) {
+        for (int i = tid; i < N; i += blockDim.x)
+          if ((eflag[i >> 5] >> (i & 31)) & 1u) {
+            const double d = (double)vals[i] - mean_e;
+            sse += d * d;
+          }
+      } else {
+        for (int i = tid; i < npix; i += blockDim.x) {
+          const int yy = o.y0 + i / w, xx = o.x0 + i % w;
+          const size_t idx = (size_t)yy * a.X + xx;
+          if (lab[idx] != L) continue;
+          const int yu = max(yy - 1, 0), yd = min(yy + 1, a.Y - 1);
+          const int xl = max(xx - 1, 0), xr = min(xx + 1, a.X - 1);
+          const bool e = lab[(size_t)yu * a.X + xx] != L || lab[(size_t)yd * a.X + xx] != L ||
+                         lab[(size_t)yy * a.X + xl] != L || lab[(size_t)yy * a.X + xr] != L;
+          if (e) {
+            const double d = (double)px_load<T>(px, idx) - mean_e;
+            sse += d * d;
+          }
+        }
+      }
+      SSE = block_sum_f64(sse, red_d);
+    }
+
     // ---- sort staged values (pad with +inf) --------------------------------
     const int n2 = next_pow2(N);
     for (int i = N + tid; i < n2; i += blockDim.x) vals[i] = INFINITY;
@@ -135,25 +203,6 @@ __global__ __launch_bounds__(256) void k_intensity(IntensityArgs a) {
       ss += d * d;
     }
     const double SS = block_sum_f64(ss, red_d);
-
-    double SSE = 0;
-    if (a.edge) {
-      double sse = 0;
-      for (int i = tid; i < npix; i += blockDim.x) {
-        const int yy = o.y0 + i / w, xx = o.x0 + i % w;
-        const size_t idx = (size_t)yy * a.X + xx;
-        if (lab[idx] != L) continue;
-        const int yu = max(yy - 1, 0), yd = min(yy + 1, a.Y - 1);
-        const int xl = max(xx - 1, 0), xr = min(xx + 1, a.X - 1);
-        const bool e = lab[(size_t)yu * a.X + xx] != L || lab[(size_t)yd * a.X + xx] != L ||
-                       lab[(size_t)yy * a.X + xl] != L || lab[(size_t)yy * a.X + xr] != L;
-        if (e) {
-          const double d = (double)px_load<T>(px, idx) - mean_e;
-          sse += d * d;
-        }
-      }
-      SSE = block_sum_f64(sse, red_d);
-    }
 
     // ---- quartiles ----------------------------------------------------------
     if (tid < 3) {
@@ -267,7 +316,7 @@ extern "C" int aliby_features_intensity(aliby_ctx* ctx, const uint16_t* labels, 
   while (cap < max_area) cap <<= 1;
   a.cap = cap;
   hipStream_t s = as_stream(stream);
-  const size_t lds_need = (size_t)cap * sizeof(float);
+  const size_t lds_need = ((size_t)cap + cap / 32 + 1) * sizeof(float);  // values + one edge bit each
   const size_t lds_cap = 128 * 1024;
   if (lds_need <= lds_cap) {
     a.gscratch = nullptr;
@@ -285,7 +334,7 @@ extern "C" int aliby_features_intensity(aliby_ctx* ctx, const uint16_t* labels, 
     }
   } else {
     int g = n_obj < 512 ? n_obj : 512;
-    int rc = aliby_ensure_scratch(ctx, (size_t)g * cap * sizeof(float));
+    int rc = aliby_ensure_scratch(ctx, (size_t)g * (cap + cap / 32 + 1) * sizeof(float));
     if (rc) return rc;
     a.gscratch = (float*)ctx->scratch;
     dim3 grid(g), block(256);

@@ -51,6 +51,8 @@ if files:
     def grp(k):
         if k.startswith("k_conv_pair32"):
             return "conv3x3_mfma_pair"
+        if k.startswith("k_conv3x3_deep"):
+            return "conv3x3_mfma_deep"
         if k.startswith("k_conv3x3"):
             params = k.split("(")[0].rstrip(">").split("<")[-1].split(", ")
             if k.startswith("k_conv3x3<") and len(params) == 8 and params[7] == "true":
@@ -91,6 +93,8 @@ def conv_group(k):  # same split as fused_unet._launch_unit / _unit_head: 128-ou
         return "conv3x3_mfma_pair"
     if not k.startswith("k_conv3x3"):
         return None
+    if k.startswith("k_conv3x3_deep"):
+        return "conv3x3_mfma_deep"
     params = k.split("(")[0].rstrip(">").split("<")[-1].split(", ")
     if k.startswith("k_conv3x3<") and len(params) == 8 and params[7] == "true":
         return "conv3x3_mfma_head"
