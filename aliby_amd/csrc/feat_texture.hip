@@ -17,6 +17,7 @@
 // (p_x, p_{x+y}, p_{x-y}) are integer LDS histograms, so every statistic is exact-integer counts
 // divided once by the total: no atomics on floats, run-to-run deterministic.
 #include "common.h"
+#include <atomic>
 
 typedef unsigned short u16;
 
@@ -50,7 +51,20 @@ __device__ __forceinline__ int grey_of(float v, int gl) {
   return q;
 }
 
-__device__ __forceinline__ double plog2p(double p) { return p > 0 ? p * log2(p) : 0.0; }
+// Every probability of the co-occurrence statistics is an integer count over the total T, so p log2(p) is
+// (c / T) (log2 c - log2 T): log2 of the integers below 2^16 comes from a table in device memory (512 KB, L2-resident,
+// filled once per device with the same log2() it replaces); the fp64 log2 sequence was most of the kernel's instructions.
+#define TX_LOGTAB 65536
+__device__ double g_log2_int[TX_LOGTAB];
+__global__ void k_init_log2_table() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < TX_LOGTAB) g_log2_int[i] = i > 0 ? log2((double)i) : 0.0;
+}
+__device__ __forceinline__ double log2_int(int n) { return n < TX_LOGTAB ? g_log2_int[n] : log2((double)n); }
+// (c / T) log2(c / T), logT = log2(T)
+__device__ __forceinline__ double plog2p_count(int c, double Tt, double logT) {
+  return c > 0 ? ((double)c / Tt) * (log2_int(c) - logT) : 0.0;
+}
 
 template <typename T, bool GLOBAL>
 __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
@@ -86,12 +100,25 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
 
     __syncthreads();
     int gmax = 0;
-    for (int i = tid; i < npix; i += blockDim.x) {
-      const size_t idx = (size_t)(o.y0 + i / w) * a.X + (o.x0 + i % w);
-      int q = 0;
-      if (lab[idx] == L) q = grey_of(px[idx], a.gray_levels);
-      g[i] = (unsigned char)q;
-      gmax = max(gmax, q);
+    // (the loads of four pixels are issued together: one memory latency per batch, see feat_intensity.hip)
+    for (int i0 = tid; i0 < npix; i0 += 4 * blockDim.x) {
+      u16 lb[4];
+      T pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * (int)blockDim.x, npix - 1);
+        const size_t idx = (size_t)(o.y0 + i / w) * a.X + (o.x0 + i % w);
+        lb[u] = lab[idx];
+        pv[u] = px[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i >= npix) break;
+        const int q = lb[u] == L ? grey_of(pv[u], a.gray_levels) : 0;
+        g[i] = (unsigned char)q;
+        gmax = max(gmax, q);
+      }
     }
     const int maxv = block_max_i32(gmax, red_i) + 1;  // side of mahotas' matrix: max grey level + 1
     __syncthreads();
@@ -175,6 +202,7 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
         continue;
       }
       const double Tt = 2.0 * (double)NP;
+      const double logT = log2_int(2 * NP);
       if (!dense) {
         const int n2 = next_pow2(NP);
         for (int i = NP + tid; i < n2; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
@@ -186,15 +214,13 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
       auto cell1 = [&](int c, int lo, int hi) {  // c pixel pairs with the unordered grey-level pair (lo, hi)
         if (lo == hi) {
           atomicAdd(&hx[lo], 2 * c);
-          const double p = 2.0 * c / Tt;
           acc[0] += 4.0 * (double)c * (double)c;
-          acc[2] += plog2p(p);
+          acc[2] += plog2p_count(2 * c, Tt, logT);
         } else {
           atomicAdd(&hx[lo], c);
           atomicAdd(&hx[hi], c);
-          const double p = (double)c / Tt;
           acc[0] += 2.0 * (double)c * (double)c;
-          acc[2] += 2.0 * plog2p(p);
+          acc[2] += 2.0 * plog2p_count(c, Tt, logT);
         }
         atomicAdd(&hplus[lo + hi], 2 * c);
         atomicAdd(&hminus[hi - lo], 2 * c);
@@ -237,14 +263,14 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
         const double pxk = (double)hx[k] / Tt;
         m[0] += (double)k * pxk;
         m[1] += (double)k * (double)k * pxk;
-        m[2] += plog2p(pxk);
+        m[2] += plog2p_count(hx[k], Tt, logT);
       }
       for (int k = tid; k <= maxlev - minlev; k += blockDim.x) {  // |i - j| never exceeds the level range
         const double pm = (double)hminus[k] / Tt;
         m[3] += (double)k * (double)k * pm;
         m[4] += pm / (1.0 + (double)k * (double)k);
         if (k < maxv) { m[5] += pm; m[6] += pm * pm; }
-        m[7] += plog2p(pm);
+        m[7] += plog2p_count(hminus[k], Tt, logT);
       }
       block_sum_vec_all<8>(m, vec);
       double s[3] = {0, 0, 0};  // sum average, sum k^2 p_plus, sum entropy (sum p log p)
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
         const double pp = (double)hplus[k] / Tt;
         s[0] += (double)k * pp;
         s[1] += (double)k * (double)k * pp;
-        s[2] += plog2p(pp);
+        s[2] += plog2p_count(hplus[k], Tt, logT);
       }
       block_sum_vec_all<3>(s, vec);
 
@@ -262,7 +288,7 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
         for (int idx = tid; idx < ncell; idx += blockDim.x) {
           int c, lo, hi;
           dense_cell(idx, c, lo, hi);
-          if (c) hxy += (2.0 * (double)c / Tt) * log2(((double)hx[lo] / Tt) * ((double)hx[hi] / Tt));
+          if (c) hxy += (2.0 * (double)c / Tt) * (log2_int(hx[lo]) + log2_int(hx[hi]) - 2.0 * logT);
         }
       } else {
         for (int i = tid; i < NP; i += blockDim.x) {
@@ -272,8 +298,7 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
           while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (keys[mid] == key) lo_ = mid + 1; else hi_ = mid; }
           const int c = lo_ - i;
           const int lo = (int)(key >> 8), hi = (int)(key & 255u);
-          const double pl = (double)hx[lo] / Tt, ph = (double)hx[hi] / Tt;
-          hxy += (2.0 * (double)c / Tt) * log2(pl * ph);
+          hxy += (2.0 * (double)c / Tt) * (log2_int(hx[lo]) + log2_int(hx[hi]) - 2.0 * logT);
         }
       }
       double hv[1] = {hxy};
@@ -331,6 +356,16 @@ extern "C" int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, co
   a.cap_cells = max_area < 65536 ? 2 * ck : 0;
   const size_t need = (size_t)a.cap_pix + (size_t)ck * 4;
   hipStream_t s = as_stream(stream);
+  {
+    static std::atomic<unsigned long long> ready{0};  // one bit per device
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (!(ready.load(std::memory_order_acquire) & bit)) {
+      hipLaunchKernelGGL(k_init_log2_table, dim3(TX_LOGTAB / 256), dim3(256), 0, s);
+      KERNEL_CHECK();
+      HIP_TRY(hipStreamSynchronize(s));  // other streams may run this kernel next
+      ready.fetch_or(bit, std::memory_order_release);
+    }
+  }
   if (need <= 96 * 1024) {
     a.gscratch = nullptr;
     dim3 grid(n_obj), block(aliby_pick_block((long long)max_h * max_w));

@@ -302,6 +302,7 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
     fan.fork()
     done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
     copies, after = [], []
+    sizeshape_col0 = next((c0 for inst, reg, kw, c0, _ in specs if inst[-1] == "sizeshape"), None)
     cell_cache = {}
     for spec in specs:
         inst, reg, kw, col0, ncols = spec
@@ -313,7 +314,12 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
             if ch != "None" and cache is not None:
                 cache.get(red_z)  # the reference would still reduce (and raise on a bad reducer)
             key = (metric, tuple(sorted(kw.items())))
-            if key in done:
+            if metric == "feret" and sizeshape_col0 is not None:
+                # the two Feret diameters are columns of the sizeshape block (one hull kernel writes both): copy them
+                ss = feat.sizeshape_names()
+                for j, name in enumerate(feat.feret_names()):
+                    copies.append((col0 + j, sizeshape_col0 + ss.index(name), 1))
+            elif key in done:
                 # e.g. "feret"/"zernike" listed under every channel: same labels, same numbers
                 copies.append((col0, done[key], ncols))
             else:
