@@ -228,9 +228,19 @@ __global__ void k_assign(const int* __restrict__ pt, const u64* __restrict__ M1,
       if (m) lab = (unsigned int)((m - 1ull) & 0xFFFFFFFFull) + 1u;
     }
     M0[i] = lab;
-    if (lab) {
-      atomicAdd(&cnt[f * s.PP + lab - 1], 1);
-      atomicMin(&firstpos[f * s.PP + lab - 1], p);
+    // Neighbouring lanes are neighbouring pixels, mostly of the same mask: one atomic pair per RUN of equal labels inside the
+    // wave instead of one per pixel (a ~20-pixel mask row was 20 atomics on one address).  Integer atomics: same result.
+    const int lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long key = ((unsigned long long)f << 32) | lab;
+    const unsigned long long prev = __shfl_up(key, 1, WAVE);
+    const bool head = lab && (lane == 0 || prev != key);
+    // run boundaries: a head, any background lane, any lane past the end of the batch
+    const unsigned long long heads = __ballot(head || !lab) | ~__ballot(1);
+    if (head) {
+      const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int run = after ? __ffsll((long long)after) : 64 - lane;  // lanes up to the next boundary (or the end of the wave)
+      atomicAdd(&cnt[f * s.PP + lab - 1], run);
+      atomicMin(&firstpos[f * s.PP + lab - 1], p);  // the head is the run's first raster position
     }
   }
 }

@@ -143,7 +143,7 @@ def main():
                     "runs as a replayed hipGraph (the product path); the line then carries no roofline objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the through-the-step-API leg (value_api)")
-    ap.add_argument("--api-fovs", type=int, default=0, help="positions of the API leg (default: 3 batches of --fovs)")
+    ap.add_argument("--api-fovs", type=int, default=0, help="positions of the API leg (default: 8 batches of --fovs)")
     ap.add_argument("--overlap", action="store_true", help="experiment: dynamics + features of step k on a second stream while the "
                     "network of step k+1 runs (software pipelining across steps)")
     ap.add_argument("--host-procs", type=int, default=0, help="host processes for input generation / the CPU baseline (default: all)")
@@ -450,7 +450,7 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
     from aliby_amd import runner
     from aliby_amd.pipe_builder import build_pipeline_steps
 
-    n_pos = args.api_fovs or 3 * B
+    n_pos = args.api_fovs or 8 * B  # (>= 4 batches: run_positions then writes parquet from worker processes)
     dev = torch.device("cuda", torch.cuda.current_device())
     dP_d = torch.stack([torch.from_numpy(b["dP"]) for b in base]).to(dev)
     prob_d = torch.stack([torch.from_numpy(b["prob"]) for b in base]).to(dev)

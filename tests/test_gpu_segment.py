@@ -207,6 +207,26 @@ def test_fused_unet_matches_module_forward(engine):
         assert err < 0.03, (levels, float(err))
         assert ((s - s_ref).norm() / s_ref.norm()) < 0.03
         print("fused unet", levels, "rel l2 err vs fp32 module:", float(err))
+    # deep levels: the K-loop unit (fp32 accumulation over the whole 9*CIN reduction, csrc/nn_conv_deep.hip) against round 1's
+    # K/N-slice launches, whose partial sums were rounded to bf16 in HBM between slices: the error against the fp32 module
+    # must not be larger, and both numbers are recorded for DESIGN.md
+    kloop, ksplit = FusedUNet(net, engine), FusedUNet(net, engine)
+    ksplit.deep_kernel = False
+    assert kloop.deep_kernel
+    errs = {}
+    for name, f in (("k_loop", kloop), ("k_split", ksplit)):
+        y, _ = f(x)
+        errs[name] = float((y - y_ref).norm() / y_ref.norm())
+        errs[name + "_max_abs"] = float((y - y_ref).abs().max())
+    print("deep levels, rel l2 err vs fp32 module:", errs)
+    assert errs["k_loop"] <= errs["k_split"] * 1.02, errs
+    try:
+        import json, pathlib
+
+        pathlib.Path("gpurun_out").mkdir(exist_ok=True)
+        pathlib.Path("gpurun_out/unet_error_kloop_vs_ksplit.json").write_text(json.dumps(errs))
+    except OSError:
+        pass
     # the output head in the last unit's epilogue gives the bits of the separate head kernel
     with_head = FusedUNet(net, engine)
     separate = FusedUNet(net, engine)
