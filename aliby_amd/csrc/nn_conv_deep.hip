@@ -230,8 +230,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
         if constexpr (i + DC_WDEPTH - 1 < NW) wring[(i + DC_WDEPTH - 1) % DC_WDEPTH] = wfrag(i + DC_WDEPTH - 1);
         sfor<DC_NB>([&](auto bc) {
           constexpr int b = decltype(bc)::value, f = i * DC_NB + b;
+#ifdef DC_HACK_HALF_LDS
+          if constexpr (f % 2 == 0 && f + 2 < NF) pring[(f + 2) % DC_PDEPTH] = pfrag(f + 2);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[(f & ~1) % DC_PDEPTH], acc[b], 0, 0, 0);
+#else
           if constexpr (f + DC_PDEPTH - 1 < NF) pring[(f + DC_PDEPTH - 1) % DC_PDEPTH] = pfrag(f + DC_PDEPTH - 1);
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], acc[b], 0, 0, 0);
+#endif
         });
         __builtin_amdgcn_sched_barrier(0);
       });
