@@ -5,7 +5,7 @@ Why a process: writing a thousand-column table with pyarrow holds the interprete
 THREADS stop scaling at three (measured on the MI355X box: 21 -> 7 ms per file at 4 threads, still 7 ms at 16), while the
 device produces a position every ~2 ms.  Processes scale (2 ms per file at 12).  The table travels by reference: the parent
 puts one Arrow IPC stream per device batch into /dev/shm, a worker maps it (zero-copy), slices its position's rows and makes
-the reference's own call — `pyarrow.parquet.write_table(table, file, compression="zstd")` (pipe_core.py:412-413).
+the reference's call (pipe_core.py:412-413: parquet, zstd) through `aliby_amd.io.write.write_profiles`.
 
 Protocol, one JSON object per line: {"ipc": path, "parts": [[row0, n], ...], "out": path} -> {"ok": true} | {"ok": false, "error": "..."}.
 The worker imports pyarrow only (no torch, no GPU) and exits when stdin closes.
@@ -20,7 +20,8 @@ from pathlib import Path
 
 def main() -> int:
     import pyarrow as pa
-    import pyarrow.parquet as pq
+
+    from aliby_amd.io.write import write_profiles
 
     opened: dict = {}  # ipc path -> table (memory-mapped); the two most recent batches
     out = sys.stdout
@@ -41,7 +42,7 @@ def main() -> int:
             profiles = parts[0] if len(parts) == 1 else pa.concat_tables(parts)
             target = Path(task["out"])
             target.parent.mkdir(parents=True, exist_ok=True)
-            pq.write_table(profiles, target, compression="zstd")
+            write_profiles(profiles, target)
             del parts, profiles
             out.write('{"ok": true}\n')
         except Exception as exc:  # reported to the parent, which raises it in the caller's thread

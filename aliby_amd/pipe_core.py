@@ -32,7 +32,7 @@ from aliby_amd.extraction.extract import (
     process_tree_masks,
     process_tree_masks_overlap,
 )
-from aliby_amd.io.write import dispatch_write_fn
+from aliby_amd.io.write import dispatch_write_fn, write_profiles
 from aliby_amd.tile.tiler import dispatch_image, dispatch_tiler
 
 logger = logging.getLogger("aliby")
@@ -271,7 +271,7 @@ def _run_pipeline_and_post_impl(pipeline: dict, pipeline_name: str, output_path,
     state = run_pipeline_return_state(pipeline, output_path / "steps" / pipeline_name, init_step_fn)
     profiles = get_profiles_from_state(state, pipeline)
     profiles_file.parent.mkdir(parents=True, exist_ok=True)
-    pyarrow.parquet.write_table(profiles, profiles_file, compression="zstd")
+    write_profiles(profiles, profiles_file)
     if post_state_hook is not None:
         post_state_hook(state, pipeline, output_path, pipeline_name)
     return profiles, {}

@@ -35,7 +35,7 @@ import pyarrow.parquet
 
 from aliby_amd import devcache, pipe_core
 from aliby_amd.extraction import extract as ex
-from aliby_amd.io.write import dispatch_write_fn
+from aliby_amd.io.write import dispatch_write_fn, write_profiles
 
 
 class _Position:
@@ -127,12 +127,17 @@ class _ArenaRing:
     def __init__(self, n=3):
         self.lock = threading.Condition()
         self.free = [_Arena(self) for _ in range(n)]
+        self.waited = 0.0
 
     def acquire(self, positions):
+        import time
+
+        t0 = time.perf_counter()
         with self.lock:
             while not self.free:
                 self.lock.wait()
             arena = self.free.pop(0)
+        self.waited += time.perf_counter() - t0  # back-pressure: the launch thread was ahead of the writers by n batches
         arena.left = positions
         return arena
 
@@ -621,7 +626,7 @@ class BatchRunner:
             t0 = time.perf_counter()
             with self._timed("write: parquet (zstd)"):
                 pos.profiles_file.parent.mkdir(parents=True, exist_ok=True)
-                pyarrow.parquet.write_table(profiles, pos.profiles_file, compression="zstd")
+                write_profiles(profiles, pos.profiles_file)
             self._tick("parquet in this process", t0)
         t0 = time.perf_counter()
         for f in pos.pending:
@@ -725,13 +730,15 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
     cores = hostinfo.usable_cores()
     if writer_processes is None or writer_processes is True:
         # parquet goes to processes once the job is large enough to pay for their start-up (an interpreter + a pyarrow import
-        # each); the launch thread, the ingest thread and the .npz threads keep a quarter of the share
+        # each).  Half the share each for the parquet processes and the writer threads (.npz compression, pivot, IPC export):
+        # measured on the 16-core share of a one-GPU box, (threads, processes) = (4, 12) 264, (6, 10) 274, (8, 8) 314,
+        # (10, 6) 245 positions/s (scripts/api_sweep.sh)
         big = writer_processes is True or (len(todo) >= 4 * batch_size and not measure)
-        writer_processes = int(os.environ.get("ALIBY_WRITER_PROCS", max(1, cores - max(4, cores // 4)))) if big else 0
+        writer_processes = int(os.environ.get("ALIBY_WRITER_PROCS", max(1, cores // 2))) if big else 0
     if measure:
         writer_processes = 0
     if writers is None:
-        writers = int(os.environ.get("ALIBY_WRITERS", max(2, cores // 4) if writer_processes else max(2, cores - 4)))
+        writers = int(os.environ.get("ALIBY_WRITERS", max(2, cores - writer_processes) if writer_processes else max(2, cores - 4)))
     runner = BatchRunner(init_step_fn, writers=writers, measure=measure, writer_processes=writer_processes)
     futures = []
     measured_from = 0
@@ -778,6 +785,7 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
             out[pos.index] = fut.result()
         clock["drain_writers_s"] = time.perf_counter() - t0
         if stats is not None:
+            clock["of_which_waiting_for_a_free_arena_s"] = runner._ring.waited
             stats.update({k: round(v, 4) for k, v in clock.items()}, batches=len(batches), writers=writers,
                          writer_processes=int(runner.writer_processes),
                          writer_thread_seconds={k: round(v, 3) for k, v in runner.thread_seconds.items()})
