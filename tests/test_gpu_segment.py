@@ -182,7 +182,8 @@ def test_segment_step_matches_reference_closure_semantics(engine):
 
 
 def test_fused_unet_matches_module_forward(engine):
-    """FusedUNet (HIP pointwise kernel + MIOpen convs, bf16) vs the plain fp32 module forward."""
+    """FusedUNet (the hand-written bf16 network: MFMA conv units on every level by default; with mfma_levels=() the A/B fallback of
+    library convolutions + the fused pointwise kernel) vs the plain fp32 module forward."""
     import torch
     from aliby_amd.segment.fused_unet import FusedUNet
     from aliby_amd.segment.unet import build_network
