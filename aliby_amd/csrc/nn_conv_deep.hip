@@ -157,17 +157,51 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
     };
     request(0);
 
-    // ---- accumulators start at the bias
+    // ---- accumulators start at bias + residual (as in nn_conv.hip): the residual's loads are in flight together with the first
+    // window's, behind the first staging phase, instead of twice exposed in the epilogue, which is then convert + store
     const int c0 = half * 128 + cb * 32 + hh * 16;
+    const int ocs = a.COUT / 8;
     f32x16_t acc[DC_NB];
     {
       float b16[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) b16[k] = a.bias ? a.bias[c0 + k] : 0.f;
+      if (a.res) {
+        const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
+        uint4 rr[DC_NB][2];
+        {
+          const int q = q0 + px;
+          int r = q / LW, c = q - r * LW;
+          int n = (r - 1) / HP, y = (r - 1) - n * HP;  // r >= 1 always: q >= q_begin = LW
 #pragma unroll
-      for (int b = 0; b < DC_NB; ++b)
+          for (int b = 0; b < DC_NB; ++b) {
+            // clamped: positions that are not stored (zero row / columns, past the last image) read some valid address
+            const int nn = min(n, a.N - 1), yy = min(y, a.H - 1), xx = min(max(c - 1, 0), a.W - 1);
+            const unsigned roff = (unsigned)(((nn * RH + (yy >> a.res_up)) * RW + (xx >> a.res_up)) * ocs + (c0 >> 3));
+            rr[b][0] = a.res[roff];
+            rr[b][1] = a.res[roff + 1];
+            c += 32;
+            while (c >= LW) {
+              c -= LW;
+              if (++y == HP) { y = 0; ++n; }
+            }
+          }
+        }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[b][k] = b16[k];
+        for (int b = 0; b < DC_NB; ++b) {
+          const unsigned rw[8] = {rr[b][0].x, rr[b][0].y, rr[b][0].z, rr[b][0].w, rr[b][1].x, rr[b][1].y, rr[b][1].z, rr[b][1].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[b][2 * j] = b16[2 * j] + dc_bf2f(rw[j] & 0xffffu);
+            acc[b][2 * j + 1] = b16[2 * j + 1] + dc_bf2f(rw[j] >> 16);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < DC_NB; ++b)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[b][k] = b16[k];
+      }
     }
     const bf16x8_t* wbase = reinterpret_cast<const bf16x8_t*>(a.wpk) + (size_t)(half * 4 + cb) * 9 * KCT * 64 + lane;
     DC_STAMP(1);
@@ -243,13 +277,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
       DC_STAMP(5 + 4 * s);
     }
 
-    // ---- epilogue: + residual, fp32 -> bf16, 32 contiguous bytes per lane and position.  Positions by stepping (no
-    // divisions); a half's residuals are requested together (one latency per half, not one per block)
+    // ---- epilogue: fp32 -> bf16, 32 contiguous bytes per lane and position.  Positions by stepping (no divisions)
     __builtin_amdgcn_sched_barrier(0);  // nothing of the epilogue is hoisted into the MFMA loop (it would spill there)
-    const int ocs = a.COUT / 8;
-    const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
-    unsigned okmask = 0;
-    unsigned ooff[DC_NB], roff[DC_NB];
     {
       const int q = q0 + px;
       int r = q / LW, c = q - r * LW;
@@ -258,10 +287,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
       for (int b = 0; b < DC_NB; ++b) {
         const int x = c - 1;
         const bool ok = q0 + b * 32 + px < a.q_end && y < a.H && x >= 0 && x < a.W && n < a.N;
-        okmask |= (unsigned)ok << b;
-        const int nn = min(n, a.N - 1), yy = min(y, a.H - 1), xx = min(max(x, 0), a.W - 1);
-        ooff[b] = (unsigned)(((nn * a.H + yy) * a.W + xx) * ocs + (c0 >> 3));
-        roff[b] = (unsigned)(((nn * RH + (yy >> a.res_up)) * RW + (xx >> a.res_up)) * ocs + (c0 >> 3));
+        if (ok) {
+          uint4* op = a.out + (unsigned)(((n * a.H + y) * a.W + x) * ocs + (c0 >> 3));
+          op[0] = make_uint4(dc_pack2(acc[b][0], acc[b][1]), dc_pack2(acc[b][2], acc[b][3]), dc_pack2(acc[b][4], acc[b][5]),
+                             dc_pack2(acc[b][6], acc[b][7]));
+          op[1] = make_uint4(dc_pack2(acc[b][8], acc[b][9]), dc_pack2(acc[b][10], acc[b][11]), dc_pack2(acc[b][12], acc[b][13]),
+                             dc_pack2(acc[b][14], acc[b][15]));
+        }
         c += 32;
         while (c >= LW) {
           c -= LW;
@@ -269,39 +301,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
         }
       }
     }
-    auto finish = [&](auto first, auto count) {  // blocks [first, first + count): residual loads together, then add + store
-      constexpr int B0 = decltype(first)::value, NBLK = decltype(count)::value;
-      uint4 rr[NBLK][2];
-      if (a.res) {
-#pragma unroll
-        for (int k = 0; k < NBLK; ++k) {
-          rr[k][0] = a.res[roff[B0 + k]];
-          rr[k][1] = a.res[roff[B0 + k] + 1];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NBLK; ++k) {
-        const int b = B0 + k;
-        if (a.res) {
-          const unsigned rw[8] = {rr[k][0].x, rr[k][0].y, rr[k][0].z, rr[k][0].w, rr[k][1].x, rr[k][1].y, rr[k][1].z, rr[k][1].w};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            acc[b][2 * j] += dc_bf2f(rw[j] & 0xffffu);
-            acc[b][2 * j + 1] += dc_bf2f(rw[j] >> 16);
-          }
-        }
-        if ((okmask >> b) & 1u) {
-          uint4* op = a.out + ooff[b];
-          op[0] = make_uint4(dc_pack2(acc[b][0], acc[b][1]), dc_pack2(acc[b][2], acc[b][3]), dc_pack2(acc[b][4], acc[b][5]),
-                             dc_pack2(acc[b][6], acc[b][7]));
-          op[1] = make_uint4(dc_pack2(acc[b][8], acc[b][9]), dc_pack2(acc[b][10], acc[b][11]), dc_pack2(acc[b][12], acc[b][13]),
-                             dc_pack2(acc[b][14], acc[b][15]));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    finish(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-    finish(std::integral_constant<int, 4>{}, std::integral_constant<int, DC_NB - 4>{});
     DC_STAMP(2 + 4 * S);
   }
 }
