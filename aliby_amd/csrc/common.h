@@ -70,46 +70,62 @@ __device__ __forceinline__ float px_load<uint16_t>(const uint16_t* p, size_t i) 
 template <>
 __device__ __forceinline__ float px_load<float>(const float* p, size_t i) { return p[i]; }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-  return v;
+// ---- wave-wide reductions by DPP ------------------------------------------------------------------------------------------
+// A reduction step is one VALU instruction reading a neighbour lane through the data-parallel-primitives path (row_shr within a
+// 16-lane row, row_bcast between rows) instead of a ds_bpermute round trip through the LDS crossbar per step: the per-object
+// kernels are chains of dozens of dependent wave reductions over a few hundred pixels, so the latency of a reduction is what
+// they wait for.  Scheme (gfx9 DPP): Hillis-Steele inclusive scan inside each row (shifts 1, 2, 4, 8; lanes without a source
+// take the identity), row 0's total into row 1 and row 2's into row 3 (row_bcast:15), lane 31's into rows 2-3 (row_bcast:31):
+// lane 63 holds the total, which v_readlane broadcasts.  Fixed order: deterministic.  The total is returned in EVERY lane.
+#define ALIBY_DPP_ROW_SHR(n) (0x110 + (n))
+#define ALIBY_DPP_ROW_BCAST15 0x142
+#define ALIBY_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_take(int ident, int v) {
+  return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ long long wave_sum(long long v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-  return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float ident, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
-  return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_take(long long ident, long long v) {
+  const int lo = __builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(ident >> 32), (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+  return ((long long)hi << 32) | (unsigned int)lo;
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, WAVE));
-  return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double ident, double v) {
+  return __longlong_as_double(dpp_take<CTRL, ROW_MASK>(__double_as_longlong(ident), __double_as_longlong(v)));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, WAVE));
-  return v;
+__device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ float wave_last(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ long long wave_last(long long v) {
+  const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+  return ((long long)hi << 32) | (unsigned int)lo;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, WAVE));
-  return v;
+__device__ __forceinline__ double wave_last(double v) { return __longlong_as_double(wave_last(__double_as_longlong(v))); }
+
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce_dpp(T v, T ident, Op op) {
+  v = op(v, dpp_take<ALIBY_DPP_ROW_SHR(1), 0xf>(ident, v));
+  v = op(v, dpp_take<ALIBY_DPP_ROW_SHR(2), 0xf>(ident, v));
+  v = op(v, dpp_take<ALIBY_DPP_ROW_SHR(4), 0xf>(ident, v));
+  v = op(v, dpp_take<ALIBY_DPP_ROW_SHR(8), 0xf>(ident, v));
+  v = op(v, dpp_take<ALIBY_DPP_ROW_BCAST15, 0xa>(ident, v));
+  v = op(v, dpp_take<ALIBY_DPP_ROW_BCAST31, 0xc>(ident, v));
+  return wave_last(v);
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v = max(v, __shfl_down(v, o, WAVE));
-  return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int o = WAVE / 2; o > 0; o >>= 1) v = min(v, __shfl_down(v, o, WAVE));
-  return v;
-}
+
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce_dpp(v, 0.0, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ long long wave_sum(long long v) { return wave_reduce_dpp(v, 0LL, [](long long a, long long b) { return a + b; }); }
+__device__ __forceinline__ int wave_sum(int v) { return wave_reduce_dpp(v, 0, [](int a, int b) { return a + b; }); }
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce_dpp(v, INFINITY, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce_dpp(v, -INFINITY, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce_dpp(v, (double)-INFINITY, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ int wave_max(int v) { return wave_reduce_dpp(v, INT_MIN, [](int a, int b) { return max(a, b); }); }
+__device__ __forceinline__ int wave_min(int v) { return wave_reduce_dpp(v, INT_MAX, [](int a, int b) { return min(a, b); }); }
 
 // Block-wide reductions.  `red` is an LDS array of >= blockDim.x/64 elements of T.
 // Deterministic: fixed tree inside the wave, then wave 0 folds the per-wave partials
