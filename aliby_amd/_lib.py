@@ -108,6 +108,7 @@ _SIGNATURES = {
     "aliby_features_feret": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "aliby_object_mec": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "aliby_features_zernike": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "aliby_features_radial_zernikes_multi": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "aliby_features_texture": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_radial_geometry": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "aliby_features_radial_distribution": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),

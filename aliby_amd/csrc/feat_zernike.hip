@@ -328,6 +328,174 @@ __global__ __launch_bounds__(256) void k_zernike(ZernikeArgs a) {
   }
 }
 
+// -----------------------------------------------------------------------------------------------
+// radial_zernikes of several channels in one launch: the channel-independent part of a pixel's work — unit-disc
+// coordinates, the powers (y + i x)^m and the 30 radial polynomials (80 of the ~170 fp64 operations per pixel and channel) —
+// is evaluated once and applied to every channel's weight.  NCH channels x 2 x KP accumulators stay below 64 doubles per
+// lane, so the 30 terms (m-major order) are cut into passes of KP = 15 / 10 / 8 / 6 terms for 2 / 3 / 4 / 5 channels.
+// Same operation order per accumulator as k_zernike: the numbers are the same bits.
+// -----------------------------------------------------------------------------------------------
+struct ZTerms { int n[ZK], m[ZK], col[ZK]; };
+__host__ __device__ constexpr ZTerms make_zterms() {
+  ZTerms z{};
+  int j = 0;
+  for (int m = 0; m <= 9; ++m)
+    for (int n = m; n < 10; n += 2) { z.n[j] = n; z.m[j] = m; z.col[j] = zidx(n, m); ++j; }
+  return z;
+}
+constexpr ZTerms ZT = make_zterms();
+__device__ __constant__ const ZTerms d_zterms = make_zterms();
+
+struct ZernikeMultiArgs {
+  const u16* labels;
+  const void* planes;  // [F,C,Y,X]
+  int F, C, Y, X;
+  int nch, channel[8], col0[8];
+  const aliby_object* tab;
+  int n_obj;
+  const double* mec;
+  double* out;
+  int ld;
+};
+
+template <typename T, int NCH, int T0, int T1>
+__device__ __forceinline__ void zern_pass_multi(const ZernikeMultiArgs& a, const aliby_object& o, bool valid, int lane, double ci, double cj,
+                                                double rad, const u16* lab, const T* const (&px)[NCH], double* wred, double* res) {
+  constexpr int KP = T1 - T0, V = 2 * KP * NCH;
+  double acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0;
+  if (valid) {
+    const int h = o.y1 - o.y0, w = o.x1 - o.x0, npix = h * w;
+    const u16 L = (u16)o.label;
+    int r = lane / w, c = lane - r * w;
+    for (int i = lane; i < npix; i += 64) {
+      const int yy = o.y0 + r, xx = o.x0 + c;
+      const size_t idx = (size_t)yy * a.X + xx;
+      c += 64;
+      while (c >= w) { c -= w; ++r; }
+      if (lab[idx] != L) continue;
+      const double y = ((double)yy - ci) / rad, x = ((double)xx - cj) / rad;
+      const double r2 = x * x + y * y;
+      if (r2 > 1.0 + 1e-9) continue;  // (the guard band of k_zernike)
+      double wgt[NCH];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) wgt[ch] = (double)px_load<T>(px[ch], idx);
+      double zr = 1.0, zi = 0.0;
+#pragma unroll
+      for (int m = 1; m <= ZT.m[T0]; ++m) { const double nr = zr * y - zi * x; zi = zr * x + zi * y; zr = nr; }
+#pragma unroll
+      for (int t = T0; t < T1; ++t) {
+        if (t > T0 && ZT.m[t] != ZT.m[t - 1]) { const double nr = zr * y - zi * x; zi = zr * x + zi * y; zr = nr; }
+        const int n = ZT.n[t], m = ZT.m[t];
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < ZW; ++q) if (q <= (n - m) / 2) s = s * r2 + zlut(n, m, q);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+          const double sw = s * wgt[ch];
+          acc[((t - T0) * NCH + ch) * 2] += sw * zr;
+          acc[((t - T0) * NCH + ch) * 2 + 1] += sw * zi;
+        }
+      }
+    }
+  }
+  constexpr int NCHUNK = (V + 15) / 16;
+#pragma unroll
+  for (int ck = 0; ck < NCHUNK; ++ck) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) wred[lane * ZROW + t] = (ck * 16 + t < V) ? acc[(ck * 16 + t < V) ? ck * 16 + t : 0] : 0.0;
+    __syncthreads();
+    const int col = lane & 15, part = lane >> 4;
+    double s = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += wred[(part * 16 + q) * ZROW + col];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const int slot = ck * 16 + col;
+    if (part == 0 && slot < V) res[2 * NCH * T0 + slot] = s;  // res[(term * NCH + channel) * 2 + {re, im}], terms m-major
+  }
+}
+
+template <int NCH>
+struct ZMultiCfg {
+  static constexpr int KP = NCH <= 2 ? 15 : NCH == 3 ? 10 : NCH == 4 ? 8 : 6;
+  static constexpr int NPASS = (ZK + KP - 1) / KP;
+};
+
+template <typename T, int NCH, int P>
+__device__ __forceinline__ void zern_passes_multi(const ZernikeMultiArgs& a, const aliby_object& o, bool valid, int lane, double ci, double cj,
+                                                  double rad, const u16* lab, const T* const (&px)[NCH], double* wred, double* res) {
+  constexpr int KP = ZMultiCfg<NCH>::KP;
+  if constexpr (P < ZMultiCfg<NCH>::NPASS) {
+    constexpr int T0 = P * KP, T1 = (T0 + KP < ZK) ? T0 + KP : ZK;
+    zern_pass_multi<T, NCH, T0, T1>(a, o, valid, lane, ci, cj, rad, lab, px, wred, res);
+    zern_passes_multi<T, NCH, P + 1>(a, o, valid, lane, ci, cj, rad, lab, px, wred, res);
+  }
+}
+
+// one WAVE per object (4 objects per 256-thread workgroup), NCH channels
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void k_zernike_multi(ZernikeMultiArgs a) {
+  __shared__ double s_wred[4][64 * ZROW];
+  __shared__ double s_res[4][2 * ZK * NCH];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t plane = (size_t)a.Y * a.X;
+  for (int base = blockIdx.x * 4; base < a.n_obj; base += gridDim.x * 4) {
+    const int oi = base + wv;
+    const bool inrange = oi < a.n_obj;
+    aliby_object o;
+    o.area = 0;
+    o.tile = 0;
+    if (inrange) o = a.tab[oi];
+    const bool valid = inrange && o.area > 0;
+    double ci = 0, cj = 0, rad = 1;
+    const u16* lab = nullptr;
+    const T* px[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) px[ch] = nullptr;
+    if (valid) {
+      ci = a.mec[(size_t)oi * 4 + 0]; cj = a.mec[(size_t)oi * 4 + 1]; rad = a.mec[(size_t)oi * 4 + 2];
+      lab = a.labels + (size_t)o.tile * plane;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) px[ch] = reinterpret_cast<const T*>(a.planes) + ((size_t)o.tile * a.C + a.channel[ch]) * plane;
+    }
+    zern_passes_multi<T, NCH, 0>(a, o, valid, lane, ci, cj, rad, lab, px, s_wred[wv], s_res[wv]);
+    __syncthreads();
+    if (inrange) {
+      for (int k = lane; k < ZK * NCH; k += 64) {
+        const int t = k / NCH, ch = k - t * NCH;
+        double* out = a.out + (size_t)oi * a.ld + a.col0[ch];
+        const int col = d_zterms.col[t];
+        if (!valid) {
+          out[col] = NAN;
+          out[ZK + col] = NAN;
+        } else {
+          const double re = s_res[wv][2 * k], im = s_res[wv][2 * k + 1];
+          out[col] = sqrt(re * re + im * im) / (double)o.area;
+          out[ZK + col] = atan2(re, im);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+static int launch_zernike_multi(const ZernikeMultiArgs& a, hipStream_t s) {
+  dim3 grid((a.n_obj + 3) / 4), block(256);
+  switch (a.nch) {
+    case 2: hipLaunchKernelGGL((k_zernike_multi<T, 2>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_zernike_multi<T, 3>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_zernike_multi<T, 4>), grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_zernike_multi<T, 5>), grid, block, 0, s, a); break;
+    default: aliby_set_error("radial_zernikes: 2 to 5 channels per launch, got %d", a.nch); return ALIBY_ERR_INVALID;
+  }
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
 extern "C" {
 
 int aliby_object_mec(aliby_ctx* ctx, const uint16_t* labels, int F, int Y, int X, const aliby_object* table_dev,
@@ -381,6 +549,30 @@ int aliby_features_zernike(aliby_ctx* ctx, const uint16_t* labels, const void* p
   else hipLaunchKernelGGL((k_zernike<float, true>), grid, block, 0, s, a);
   KERNEL_CHECK();
   return ALIBY_OK;
+}
+
+/* radial_zernikes of 2..5 channels of the same planes in one launch (k_zernike_multi): channels[i] -> out[:, col0s[i] .. +60). */
+int aliby_features_radial_zernikes_multi(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C, int Y,
+                                         int X, const int* channels, const int* col0s, int n_channels, const aliby_object* table_dev,
+                                         int n_obj, const double* mec_dev, double* out, int ld, void* stream) {
+  ARG_CHECK(ctx != nullptr, "ctx is NULL");
+  if (n_obj == 0) return ALIBY_OK;
+  ARG_CHECK(labels && planes && table_dev && mec_dev && out && channels && col0s, "NULL argument");
+  ARG_CHECK(F > 0 && Y > 0 && X > 0, "bad shape");
+  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
+  ARG_CHECK(n_channels >= 2 && n_channels <= 5, "2 <= n_channels <= 5");
+  ZernikeMultiArgs a;
+  a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.nch = n_channels;
+  for (int i = 0; i < 8; ++i) { a.channel[i] = 0; a.col0[i] = 0; }
+  for (int i = 0; i < n_channels; ++i) {
+    ARG_CHECK(channels[i] >= 0 && channels[i] < C, "channel out of range");
+    ARG_CHECK(col0s[i] >= 0 && col0s[i] + 2 * ZK <= ld, "columns exceed row stride");
+    a.channel[i] = channels[i];
+    a.col0[i] = col0s[i];
+  }
+  a.tab = table_dev; a.n_obj = n_obj; a.mec = mec_dev; a.out = out; a.ld = ld;
+  hipStream_t s = as_stream(stream);
+  return dtype == ALIBY_U16 ? launch_zernike_multi<u16>(a, s) : launch_zernike_multi<float>(a, s);
 }
 
 }  // extern "C"

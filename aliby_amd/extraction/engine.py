@@ -324,6 +324,31 @@ class FeatureEngine:
             )
         return 60 if weighted else 30
 
+    def radial_zernikes_multi(self, labels, planes, dtype, channels, table: ObjectTable, out, col0s):
+        """radial_zernikes of several channels of one plane block: launches of up to five channels share the channel-independent
+        basis (aliby_features_radial_zernikes_multi); a channel left alone goes through `zernike(weighted=True)`."""
+        import ctypes as C
+
+        F, Cn, Y, X = planes.shape
+        mec = self.mec(labels, table)
+        channels, col0s = list(map(int, channels)), list(map(int, col0s))
+        k = 0
+        while k < len(channels):
+            n = min(5, len(channels) - k)
+            if len(channels) - k - n == 1:  # never leave a single channel for the last launch
+                n -= 1
+            if n == 1:
+                self.zernike(labels, planes, dtype, channels[k], table, out, col0s[k], True)
+            else:
+                ch = (C.c_int * n)(*channels[k : k + n])
+                c0 = (C.c_int * n)(*col0s[k : k + n])
+                with self.timed("radial_zernikes"):
+                    _lib.check(self.lib.aliby_features_radial_zernikes_multi(
+                        self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, ch, c0, n, _ptr(table.dev), table.n_obj,
+                        _ptr(mec), _ptr(out), out.stride(0), _stream_ptr()))
+            k += n
+        return 60
+
     def texture(self, labels, planes, dtype, channel, table: ObjectTable, out, col0, scale=3, gray_levels=256):
         F, Cn, Y, X = planes.shape
         with self.timed("texture"):

@@ -302,6 +302,7 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
     fan.fork()
     done = {}  # (metric, kwargs) of pixel-independent families already computed -> first column
     copies, after = [], []
+    zern_groups = {}  # red_z -> [(channel, first column)] of the radial_zernikes instructions
     sizeshape_col0 = next((c0 for inst, reg, kw, c0, _ in specs if inst[-1] == "sizeshape"), None)
     cell_cache = {}
     for spec in specs:
@@ -330,8 +331,15 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
             if cache is None:
                 raise Exception("pixels are required for this instruction")
             plane, dt = cache.get(red_z)
+            if metric == "radial_zernikes" and hasattr(eng, "radial_zernikes_multi") and table.n_obj:
+                zern_groups.setdefault(red_z, []).append((ch, col0))  # channels of one plane block share a launch (below)
+                continue
             with fan.next_stream():
                 reg["launch"](eng, labels, table, plane, dt, ch, out, col0, kw)
+    for red_z, members in zern_groups.items():
+        plane, dt = cache.get(red_z)
+        with fan.next_stream():
+            eng.radial_zernikes_multi(labels, plane, dt, [c for c, _ in members], table, out, [c0 for _, c0 in members])
     fan.join()
     for col0, src, ncols in copies:
         out[:, col0 : col0 + ncols] = out[:, src : src + ncols]

@@ -322,6 +322,12 @@ int aliby_features_zernike(aliby_ctx* ctx, const uint16_t* labels, const void* p
                            int F, int C, int Y, int X, int channel, const aliby_object* table_dev,
                            int n_obj, const double* mec_dev, int weighted, double* out, int ld, int col0,
                            void* stream);
+/* radial_zernikes (the weighted form above) of 2..5 channels of the same planes in ONE launch: the unit-disc coordinates, the
+ * powers (y + ix)^m and the radial polynomials of a pixel are evaluated once and applied to every channel's weight.
+ * channels[i] -> out[:, col0s[i] .. col0s[i] + 60); same numbers as n_channels calls of aliby_features_zernike(weighted = 1). */
+int aliby_features_radial_zernikes_multi(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype, int F, int C, int Y,
+                                         int X, const int* channels, const int* col0s, int n_channels, const aliby_object* table_dev,
+                                         int n_obj, const double* mec_dev, double* out, int ld, void* stream);
 
 /* cp_measure "texture": 13 Haralick statistics x 4 directions (direction-major, 52 columns) of the
  * object's bbox crop quantised to 8-bit grey levels (uint16 >> 8; [0,1] floats -> rint(255 f)),

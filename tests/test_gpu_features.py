@@ -380,3 +380,32 @@ def test_granularity_matches_oracle(engine):
             assert np.allclose(a, b, rtol=1e-4, atol=1e-9, equal_nan=True)
     with pytest.raises(NotImplementedError):
         process_tree_masks(tree, f["cells"], f["pixels"][None], extract_tree, cp_measure_kwargs={"granularity": {"image_mask": "objects"}})
+
+
+def test_radial_zernikes_of_several_channels_in_one_launch(engine):
+    """aliby_features_radial_zernikes_multi (the channel-independent Zernike basis evaluated once per pixel) gives the bits of
+    one aliby_features_zernike(weighted) launch per channel, for every channel count and for float pixels."""
+    import torch
+    from aliby_amd.extraction.engine import to_device_planes, to_device_u16
+
+    fovs = [synth.make_fov(2, 60 + i, shape=(256, 288), n_channels=5, n_target=20) for i in range(2)]
+    labels = np.stack([f["nuclei"] for f in fovs])
+    labels[1][labels[1] == 3] = 0  # an absent label: NaN row
+    planes_u16 = np.stack([f["pixels"][:, 0] for f in fovs])
+    for planes in (planes_u16, (planes_u16 / 65535.0).astype(np.float32)):
+        dl = to_device_u16(labels)
+        dp, dt = to_device_planes(planes)
+        tab = engine.object_table(dl)
+        for chans in ((0, 1), (4, 2, 0), (0, 1, 2, 3), (3, 1, 4, 0, 2), (0, 1, 2, 3, 4, 0, 2), (1,), (0, 1, 2, 3, 4, 1)):
+            ref = engine.new_output(tab.n_obj, 60 * len(chans) + 3)
+            got = engine.new_output(tab.n_obj, 60 * len(chans) + 3)
+            ref.fill_(-3.0)
+            got.fill_(-3.0)
+            cols = [1 + 60 * k for k in range(len(chans))]
+            for ch, c0 in zip(chans, cols):
+                engine.zernike(dl, dp, dt, ch, tab, ref, c0, True)
+            engine.radial_zernikes_multi(dl, dp, dt, chans, tab, got, cols)
+            torch.cuda.synchronize()
+            a, b = ref.cpu().numpy(), got.cpu().numpy()
+            assert np.array_equal(np.nan_to_num(a, nan=-9.0), np.nan_to_num(b, nan=-9.0)), chans
+            assert np.isnan(b).any() and (b[:, 0] == -3.0).all() and (b[:, -2:] == -3.0).all()
