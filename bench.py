@@ -120,15 +120,21 @@ def make_inputs(config, cfg, fov_ids, size, procs):
     jobs = [(config, i, size, cfg["C"], cfg["Z"], cfg["n_target"]) for i in fov_ids]
     if procs <= 1 or len(jobs) <= 1:
         return [_make_one(j) for j in jobs]
-    with mp.get_context("fork").Pool(min(procs, len(jobs))) as pool:
+    # close + join, not the context manager's terminate(): SIGTERM in a worker that inherited rocprofv3's preloaded tool runs the
+    # tool's signal handler there, and the profiled run then hangs now and then (seen twice under `rocprofv3 -- python3 bench.py`)
+    pool = mp.get_context("fork").Pool(min(procs, len(jobs)))
+    try:
         return pool.map(_make_one, jobs, chunksize=1)
+    finally:
+        pool.close()
+        pool.join()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (1-based)")
     ap.add_argument("--fovs", type=int, default=64, help="FOVs per step per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic FOVs generated per rank (replicated to --fovs)")

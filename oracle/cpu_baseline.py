@@ -68,14 +68,21 @@ def whole_tile(fov, flow, mono_tree, multi_tree, workers=None, cp_measure_kwargs
     t_explode = time.perf_counter() - t0
     t0 = time.perf_counter()
     done, per_obj, n_calls = 0, [], 0
-    with mp.get_context("fork").Pool(workers) as pool:
+    pool = mp.get_context("fork").Pool(workers)
+    stopped = False
+    try:
         for dt, n in pool.imap_unordered(_one_object, range(1, n_obj + 1), chunksize=1):
             per_obj.append(dt)
             n_calls += n
             done += 1
             if time.perf_counter() - t0 > budget_s:  # safety net on a very slow box: report what was measured
                 pool.terminate()
+                stopped = True
                 break
+    finally:
+        if not stopped:
+            pool.close()  # (workers exit by themselves: no SIGTERM, see bench.make_inputs)
+        pool.join()
     t_feat_wall = time.perf_counter() - t0
     _G.clear()
     scale = n_obj / max(done, 1)
