@@ -292,3 +292,52 @@ def test_network_graph_replay_matches_eager(engine):
     assert model.use_graph and len(model._graphs) == 2, "graph capture was refused"
     for dP, pr in outs:
         assert torch.equal(dP, dP0) and torch.equal(pr, pr0)
+
+
+def test_masks_are_stable_under_the_networks_numeric_error(engine):
+    """north_star asks for bit-exact object IDs; with random weights (no checkpoint is obtainable offline) the network's own
+    output is noise, so its effect on masks cannot be measured directly.  A proxy that can: perturb analytic flow fields by the
+    relative error the bf16 network shows against the fp32 module (0.0096 relative L2, test_fused_unet_matches_module_forward;
+    3x that as a margin) and measure how the masks move.  Recorded for DESIGN.md §4."""
+    import json
+    import pathlib
+
+    import torch
+    from aliby_amd.segment.dynamics import masks_from_flows
+
+    tiles = [_flows((512, 512), 64, fov, "nuclei") for fov in (10, 11, 12, 13)]
+    dP = np.stack([t[1] for t in tiles])
+    prob = np.stack([t[2] for t in tiles])
+    base, n0 = masks_from_flows(engine, torch.from_numpy(dP).cuda(), torch.from_numpy(prob).cuda())
+    base = base.cpu().numpy()
+    rng = np.random.default_rng(11)
+    report = {}
+    for rel in (0.0096, 0.03):
+        def noisy(a):
+            rms = float(np.sqrt(np.mean(a.astype(np.float64) ** 2)))
+            return (a + rng.normal(0.0, rel * rms, size=a.shape)).astype(np.float32)
+
+        got, n1 = masks_from_flows(engine, torch.from_numpy(noisy(dP)).cuda(), torch.from_numpy(noisy(prob)).cuda())
+        got = got.cpu().numpy()
+        same_count = int(sum(int(a) == int(b) for a, b in zip(n0, n1)))
+        ious, identical, total = [], 0, 0
+        for f in range(len(tiles)):
+            for lab in range(1, int(n0[f]) + 1):
+                m = base[f] == lab
+                other = np.bincount(got[f][m]).argmax()
+                inter = np.logical_and(m, got[f] == other).sum() if other else 0
+                union = np.logical_or(m, got[f] == other).sum() if other else m.sum()
+                ious.append(inter / union)
+                identical += int(other != 0 and inter == union)
+                total += 1
+        report[str(rel)] = dict(tiles_with_equal_object_count=same_count, objects=total, identical_masks=identical,
+                                mean_iou=float(np.mean(ious)), min_iou=float(np.min(ious)),
+                                pixels_changed=int((((base > 0) != (got > 0))).sum()), pixels=int(base.size))
+        assert same_count == len(tiles), report
+        assert np.mean(ious) > 0.97 and np.min(ious) > 0.7, report
+    print("mask stability under flow perturbation:", report)
+    try:
+        pathlib.Path("gpurun_out").mkdir(exist_ok=True)
+        pathlib.Path("gpurun_out/mask_stability.json").write_text(json.dumps(report, indent=1))
+    except OSError:
+        pass
