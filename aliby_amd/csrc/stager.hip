@@ -29,6 +29,24 @@ __global__ void k_crop_copy(CropArgs a) {
   const u16* src = a.stack + (size_t)cz * a.Y * a.X;
   u16* dst = a.out + ((size_t)f * a.C * a.Z + cz) * (size_t)a.h * a.w;
   const int n = a.h * a.w;
+  // rows of whole 16-byte groups on both sides (tile width, frame width and the rect's x origin multiples of 8 pixels, both
+  // base pointers 16-byte aligned): one uint4 per lane; anything else, and groups that straddle the frame's edge, go pixel by pixel
+  const bool vec = (a.w % 8 == 0) && (a.X % 8 == 0) && (x0 % 8 == 0) && ((((size_t)(const void*)src) | ((size_t)(void*)dst)) % 16 == 0);
+  if (vec) {
+    const int ng = n / 8, wg = a.w / 8;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += gridDim.x * blockDim.x) {
+      const int r = g / wg, q = (g - r * wg) * 8;
+      const int y = y0 + r, x = x0 + q;
+      if (y < 0 || y >= a.Y) continue;
+      if (x >= 0 && x + 8 <= a.X) {
+        *reinterpret_cast<uint4*>(dst + (size_t)g * 8) = *reinterpret_cast<const uint4*>(src + (size_t)y * a.X + x);
+      } else {
+        for (int k = 0; k < 8; ++k)
+          if (x + k >= 0 && x + k < a.X) dst[(size_t)g * 8 + k] = src[(size_t)y * a.X + x + k];
+      }
+    }
+    return;
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int r = i / a.w, q = i % a.w;
     const int y = y0 + r, x = x0 + q;
