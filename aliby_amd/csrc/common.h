@@ -168,13 +168,19 @@ __device__ __forceinline__ int sort_hi(int a, int b) { return max(a, b); }
 // i = 64 r + lane meets lane ^ j of the same register.  `k` is the run length of the merge the stage belongs to.
 template <typename T, int R>
 __device__ __forceinline__ void wave_sort_lanes(T (&v)[R], int k, int lane) {
+  // (not unrolled, here and in the callers' k loops: fully unrolled, the chains of min / max selects send LLVM's InstCombine
+  // into minutes of compile time per instantiation)
+#pragma clang loop unroll(disable)
   for (int j = (k < 64 ? k : 64) >> 1; j > 0; j >>= 1) {
     const bool lower = (lane & j) == 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const T o = __shfl_xor(v[r], j, WAVE);
       const bool up = (((r << 6) | lane) & k) == 0;
-      v[r] = (lower == up) ? sort_lo(v[r], o) : sort_hi(v[r], o);
+      // keep the smaller of (mine, partner's) when lower == up, else the larger: compare + select (as the LDS loop does; min /
+      // max intrinsics here cost minutes of InstCombine time per instantiation)
+      const bool partner_smaller = o < v[r];
+      v[r] = (partner_smaller == (lower == up)) ? o : v[r];
     }
   }
 }
@@ -189,6 +195,7 @@ __device__ __forceinline__ void wave_bitonic_sort_regs(T* a) {
   T v[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) v[r] = a[(r << 6) + lane];
+#pragma clang loop unroll(disable)
   for (int k = 2; k <= 64; k <<= 1) wave_sort_lanes<T, R>(v, k, lane);
 #pragma unroll
   for (int kr = 2; kr <= R; kr <<= 1) {  // merges of run length k = 64 kr
@@ -199,8 +206,9 @@ __device__ __forceinline__ void wave_bitonic_sort_regs(T* a) {
         if (r & jr) continue;
         const T x = v[r], y = v[r | jr];
         const bool up = (r & kr) == 0;  // compile-time: bit k of i = 64 r + lane is a bit of r
-        v[r] = up ? sort_lo(x, y) : sort_hi(x, y);
-        v[r | jr] = up ? sort_hi(x, y) : sort_lo(x, y);
+        const bool sw = (x > y) == up;
+        v[r] = sw ? y : x;
+        v[r | jr] = sw ? x : y;
       }
     }
     wave_sort_lanes<T, R>(v, kr << 6, lane);
@@ -220,7 +228,27 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n2) {
         case 2: wave_bitonic_sort_regs<T, 2>(a); break;
         case 4: wave_bitonic_sort_regs<T, 4>(a); break;
         case 8: wave_bitonic_sort_regs<T, 8>(a); break;
-        default: wave_bitonic_sort_regs<T, 16>(a); break;
+        default: {
+          // 1024 elements: both halves in registers, then one merge through LDS (a 16-register instantiation takes LLVM's
+          // InstCombine minutes to compile).  Two ascending runs merge as: compare i with 1023 - i, then half-cleaners 256 .. 1.
+          wave_bitonic_sort_regs<T, 8>(a);
+          wave_bitonic_sort_regs<T, 8>(a + 512);
+          __syncthreads();
+          const int lane = threadIdx.x & (WAVE - 1);
+          for (int i = lane; i < 512; i += WAVE) {
+            const T x = a[i], y = a[1023 - i];
+            if (x > y) { a[i] = y; a[1023 - i] = x; }
+          }
+          for (int j = 256; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = lane; t < 512; t += WAVE) {
+              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+              const T x = a[i], y = a[p];
+              if (x > y) { a[i] = y; a[p] = x; }
+            }
+          }
+          break;
+        }
       }
     } else {
       // fewer than a wave's worth: pad in registers
@@ -232,6 +260,7 @@ __device__ __forceinline__ void block_bitonic_sort(T* a, int n2) {
 #pragma unroll
       for (int o = WAVE / 2; o > 0; o >>= 1) big = sort_hi(big, __shfl_xor(big, o, WAVE));
       v[0] = lane < n2 ? keep : big;
+#pragma clang loop unroll(disable)
       for (int k = 2; k <= 64; k <<= 1) wave_sort_lanes<T, 1>(v, k, lane);
       if (lane < n2) a[lane] = v[0];
     }
