@@ -84,7 +84,8 @@ def alg_bytes(kernel, B, C, Z, Y, X, n_obj, n_tiles_net):
         "feret": B * P * 2 + n_obj * 2 * 8,
         "mec": B * P * 2 + n_obj * 32,
         "zernike": B * P * 2 + n_obj * 30 * 8,
-        "radial_zernikes": B * P * 2 * 2 + n_obj * 60 * 8,
+        # every extracted channel in one launch (aliby_features_radial_zernikes_multi): labels once + C pixel planes
+        "radial_zernikes": B * P * 2 * (1 + C) + n_obj * 60 * 8 * C if C >= 2 else B * P * 2 * 2 + n_obj * 60 * 8,
         "texture": B * P * 2 * 2 + n_obj * 52 * 8,
         "radial_geometry": B * P * 2 + B * P,
         "radial_distribution": B * P * (2 + 1 + 2) + n_obj * 12 * 8,
