@@ -219,40 +219,24 @@ __global__ __launch_bounds__(256) void k_intensity(IntensityArgs a) {
     const double med = s_res[1];
 
     // ---- MAD: k-th smallest of |v - med| without a second sort ---------------
-    // d_i = |s_i - med| is non-increasing on the left part (s_i <= med) and
-    // non-decreasing on the right; cnt(d <= t) is two binary searches.
-    int m_left;  // number of sorted values <= med
-    {
-      int lo = 0, hi = N;
-      while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)vals[mid] <= med) lo = mid + 1; else hi = mid; }
-      m_left = lo;
-    }
+    // d_i = |s_i - med| falls and then rises along the sorted list, so the j + 1 values with the smallest deviations are a
+    // WINDOW [l, l + j] of it, and the j-th smallest deviation (0-based) is the smallest, over all windows of j + 1
+    // consecutive values, of the larger end deviation: every window holds at least one of the values whose deviation is
+    // >= the answer, and the values whose deviation is <= the answer are consecutive and at least j + 1.  Two LDS reads per
+    // window and one reduction, instead of four binary searches per value.
     const double qidx = (double)N * 0.5;
     const int qi = (int)qidx;
     const double qf = qidx - floor(qidx);
     const bool interp = qi < N - 1;
-    if (tid == 0) { s_res[3] = NAN; s_res[4] = NAN; }
-    __syncthreads();
-    for (int j = tid; j < N; j += blockDim.x) {
-      const double dj = fabs((double)vals[j] - med);
-      // left part: indices [0, m_left), d non-increasing: first index with d <= t / d < t
-      int lo = 0, hi = m_left;
-      while (lo < hi) { int mid = (lo + hi) >> 1; if (med - (double)vals[mid] <= dj) hi = mid; else lo = mid + 1; }
-      const int left_le = m_left - lo;
-      lo = 0; hi = m_left;
-      while (lo < hi) { int mid = (lo + hi) >> 1; if (med - (double)vals[mid] < dj) hi = mid; else lo = mid + 1; }
-      const int left_lt = m_left - lo;
-      // right part: indices [m_left, N), d non-decreasing
-      lo = m_left; hi = N;
-      while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)vals[mid] - med <= dj) lo = mid + 1; else hi = mid; }
-      const int right_le = lo - m_left;
-      lo = m_left; hi = N;
-      while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)vals[mid] - med < dj) lo = mid + 1; else hi = mid; }
-      const int right_lt = lo - m_left;
-      const int c_lt = left_lt + right_lt, c_le = left_le + right_le;
-      if (c_lt <= qi && qi < c_le) s_res[3] = dj;            // benign race: equal values
-      if (interp && c_lt <= qi + 1 && qi + 1 < c_le) s_res[4] = dj;
+    double best0 = INFINITY, best1 = INFINITY;
+    for (int l = tid; l + qi < N; l += blockDim.x) {
+      const double dl = fabs((double)vals[l] - med);
+      best0 = fmin(best0, fmax(dl, fabs((double)vals[l + qi] - med)));
+      if (interp && l + qi + 1 < N) best1 = fmin(best1, fmax(dl, fabs((double)vals[l + qi + 1] - med)));
     }
+    const double D0 = -block_max_f64(-best0, red_d);
+    const double D1 = interp ? -block_max_f64(-best1, red_d) : NAN;
+    if (tid == 0) { s_res[3] = D0; s_res[4] = D1; }
     __syncthreads();
 
     if (tid == 0) {
