@@ -137,7 +137,7 @@ __device__ __forceinline__ int wave_min(int v) { return wave_reduce_dpp(v, INT_M
     v = WOP(v);                                                               \
     if (nw == 1) { /* single-wave workgroup: no LDS round trip */             \
       __syncthreads();                                                        \
-      return __shfl(v, 0, WAVE);                                              \
+      return v; /* (wave reductions return the total in every lane) */        \
     }                                                                         \
     __syncthreads();                                                          \
     if (lane == 0) red[wid] = v;                                              \
@@ -291,7 +291,7 @@ __device__ __forceinline__ void block_sum_vec_all(double (&v)[K], double* lds) {
   __syncthreads();
   if (nw == 1) {  // single-wave workgroup: shuffles only
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = __shfl(wave_sum(v[k]), 0, WAVE);
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);  // (the total, in every lane)
     return;
   }
 #pragma unroll

@@ -270,7 +270,7 @@ struct PairsArgs {
 template <int K>
 __device__ __forceinline__ void wave_sum_all(double (&v)[K]) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = __shfl(wave_sum(v[k]), 0, 64);
+  for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);  // (the total, in every lane)
 }
 
 template <typename T>
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_coloc_pairs(PairsArgs a) {
       }
       wave_sum_all<2>(s2);
       const double mean1 = s2[0] / dN, mean2 = s2[1] / dN;
-      const float MAX1 = __shfl(wave_max(m1), 0, 64), MAX2 = __shfl(wave_max(m2), 0, 64);
+      const float MAX1 = wave_max(m1), MAX2 = wave_max(m2);
 
       if (col_pearson >= 0) {
         double q[3] = {0, 0, 0};
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_coloc_pairs(PairsArgs a) {
           if (a1 && a2) { q[2] += f; q[3] += s; anyc = 1; }
         }
         wave_sum_all<4>(q);
-        any_comb = __shfl(wave_max(anyc), 0, 64);
+        any_comb = wave_max(anyc);
         tot1 = q[0]; tot2 = q[1];
         if (col_manders >= 0 && lane == 0) {
           out[col_manders] = any_comb ? q[2] / tot1 : 0.0;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_coloc_pairs(PairsArgs a) {
           if (fa && sa) { c4[2] += f; c4[3] += s; c_any = 1; }
         }
         wave_sum_all<4>(c4);
-        const int FA = __shfl(wave_max(f_any), 0, 64), SA = __shfl(wave_max(s_any), 0, 64), CA = __shfl(wave_max(c_any), 0, 64);
+        const int FA = wave_max(f_any), SA = wave_max(s_any), CA = wave_max(c_any);
         if (lane == 0) {
           const double d1 = FA ? c4[0] : 0.0, d2 = SA ? c4[1] : 0.0;
           out[col_costes] = CA ? c4[2] / d1 : 0.0;
