@@ -21,6 +21,19 @@
 
 typedef unsigned short u16;
 
+// next probe of CellProfiler's "faster" Costes search: floor((right - left) / 1.2) + left while the bracket is wider than 6,
+// else the midpoint.  The bounds are integers whenever scale_max is (left = 1, +-1 steps): floor(x / (6.0 / 5.0)) == (5 x) / 6
+// and floor(x / 2.0) == x / 2 for every integer 0 <= x < 2^20 (checked exhaustively in tests/test_oracle_golden.py), which
+// replaces an fp64 division per probe by integer arithmetic.
+__device__ __forceinline__ double costes_next_mid(double left, double right, bool int_bounds) {
+  if (int_bounds) {
+    const int span = (int)(right - left);
+    return (double)(span > 6 ? (5 * span) / 6 : span / 2) + left;
+  }
+  if (right - left > 6) return floor((right - left) / (6.0 / 5.0)) + left;
+  return floor((right - left) / 2.0) + left;
+}
+
 struct ColocArgs {
   const u16* labels;
   const void* planes;  // [F,C,Y,X]
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
       const double num = (yvar - xvar) + sqrt((yvar - xvar) * (yvar - xvar) + 4 * (covar * covar));
       const double ca = num / denom, cb = ymean - ca * xmean;
       double left = 1, right = a.scale_max;
+      const bool int_bounds = a.scale_max == floor(a.scale_max) && a.scale_max >= 1 && a.scale_max <= 1048576.0;
       double mid = floor((right - left) / (6.0 / 5.0)) + left;
       double lastmid = 0, valid = 1;
       for (int it = 0; it < 200 && lastmid != mid; ++it) {
@@ -208,15 +222,16 @@ __global__ __launch_bounds__(256) void k_coloc(ColocArgs a) {
             if (f < t1 || s < t2) { const double dx = f - mx, dy = s - my; p3[0] += dx * dx; p3[1] += dy * dy; p3[2] += dx * dy; }
           }
           block_sum_vec_all<3>(p3, vec);
-          const double nx = sqrt(p3[0]), ny = sqrt(p3[1]);
-          double r = NAN;
-          if (nx != 0 && ny != 0) r = fmax(fmin(p3[2] / (nx * ny), 1.0), -1.0);
-          if (r < 0) left = mid - 1;
-          else if (r >= 0) { right = mid + 1; valid = mid; }
+          // r = clip(p3[2] / (sqrt(p3[0]) sqrt(p3[1])), -1, 1) is only ever compared with 0: its sign is p3[2]'s, and it is NaN
+          // (neither bound moves) exactly when one of the variances is 0 — two fp64 square roots and a division less per
+          // probe, executed by every lane (the scalar fp64 arithmetic of a probe cost more than its passes over the pixels)
+          if (p3[0] != 0 && p3[1] != 0) {
+            if (p3[2] < 0) left = mid - 1;
+            else if (p3[2] >= 0) { right = mid + 1; valid = mid; }
+          }
         }
         lastmid = mid;
-        if (right - left > 6) mid = floor((right - left) / (6.0 / 5.0)) + left;
-        else mid = floor((right - left) / 2.0) + left;
+        mid = costes_next_mid(left, right, int_bounds);
       }
       const double t1 = (valid - 1) / a.scale_max, t2 = ca * t1 + cb;
       double c4[4] = {0, 0, 0, 0};
@@ -411,6 +426,7 @@ __global__ __launch_bounds__(256) void k_coloc_pairs(PairsArgs a) {
         const double num = (yvar - xvar) + sqrt((yvar - xvar) * (yvar - xvar) + 4 * (covar * covar));
         const double cA = num / denom, cB = ymean - cA * xmean;
         double left = 1, right = a.scale_max;
+      const bool int_bounds = a.scale_max == floor(a.scale_max) && a.scale_max >= 1 && a.scale_max <= 1048576.0;
         double mid = floor((right - left) / (6.0 / 5.0)) + left;
         double lastmid = 0, valid = 1;
         for (int it = 0; it < 200 && lastmid != mid; ++it) {
@@ -431,15 +447,13 @@ __global__ __launch_bounds__(256) void k_coloc_pairs(PairsArgs a) {
               if (f < t1 || s < t2) { const double dx = f - mx, dy = s - my; p3[0] += dx * dx; p3[1] += dy * dy; p3[2] += dx * dy; }
             }
             wave_sum_all<3>(p3);
-            const double nx = sqrt(p3[0]), ny = sqrt(p3[1]);
-            double r = NAN;
-            if (nx != 0 && ny != 0) r = fmax(fmin(p3[2] / (nx * ny), 1.0), -1.0);
-            if (r < 0) left = mid - 1;
-            else if (r >= 0) { right = mid + 1; valid = mid; }
+            if (p3[0] != 0 && p3[1] != 0) {  // (the sign of r is p3[2]'s; see k_coloc)
+              if (p3[2] < 0) left = mid - 1;
+              else if (p3[2] >= 0) { right = mid + 1; valid = mid; }
+            }
           }
           lastmid = mid;
-          if (right - left > 6) mid = floor((right - left) / (6.0 / 5.0)) + left;
-          else mid = floor((right - left) / 2.0) + left;
+          mid = costes_next_mid(left, right, int_bounds);
         }
         const double t1 = (valid - 1) / a.scale_max, t2 = cA * t1 + cB;
         double c4[4] = {0, 0, 0, 0};
