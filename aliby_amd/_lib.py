@@ -19,6 +19,7 @@ LIB_PATH = _HERE / "libaliby_hip.so"
 
 OK, ERR_INVALID, ERR_OVERFLOW, ERR_HIP, ERR_TOO_LARGE, ERR_UNSUPPORTED = range(6)
 U16, F32 = 0, 1
+U64, F64 = 2, 3  # aliby_reduce_z output dtypes (NumPy's result types for uint16 add / divide)
 RED_MAX, RED_ADD, RED_DIV = 0, 1, 2
 
 

@@ -203,8 +203,9 @@ int aliby_reduce_z(aliby_ctx* ctx, const void* in, int dtype, size_t outer, int 
     aliby_set_error("reduce_z: operator %d is an invalid reducer (only ufuncs max/add/div)", op);
     return ALIBY_ERR_UNSUPPORTED;
   }
-  const int want = (op == ALIBY_RED_MAX) ? dtype : ALIBY_F32;
-  ARG_CHECK(out_dtype == want, "out_dtype: max keeps the dtype, add/div produce f32");
+  const int numpy_out = (dtype != ALIBY_U16) ? ALIBY_F32 : (op == ALIBY_RED_ADD ? ALIBY_U64 : ALIBY_F64);
+  ARG_CHECK(op == ALIBY_RED_MAX ? out_dtype == dtype : (out_dtype == ALIBY_F32 || out_dtype == numpy_out),
+            "out_dtype: max keeps the dtype; add/div produce f32, or NumPy's own u64 (u16 add) / f64 (u16 div)");
   hipStream_t s = as_stream(stream);
   const size_t total = outer * inner;
   size_t blocks = (total + 255) / 256;
@@ -213,8 +214,8 @@ int aliby_reduce_z(aliby_ctx* ctx, const void* in, int dtype, size_t outer, int 
 #define LAUNCH(TI, TO, OP) hipLaunchKernelGGL((k_reduce_z<TI, TO, OP>), g, b, 0, s, (const TI*)in, outer, Z, inner, (TO*)out)
   if (dtype == ALIBY_U16) {
     if (op == ALIBY_RED_MAX) LAUNCH(u16, u16, ALIBY_RED_MAX);
-    else if (op == ALIBY_RED_ADD) LAUNCH(u16, float, ALIBY_RED_ADD);
-    else LAUNCH(u16, float, ALIBY_RED_DIV);
+    else if (op == ALIBY_RED_ADD) { if (out_dtype == ALIBY_U64) LAUNCH(u16, unsigned long long, ALIBY_RED_ADD); else LAUNCH(u16, float, ALIBY_RED_ADD); }
+    else { if (out_dtype == ALIBY_F64) LAUNCH(u16, double, ALIBY_RED_DIV); else LAUNCH(u16, float, ALIBY_RED_DIV); }
   } else {
     if (op == ALIBY_RED_MAX) LAUNCH(float, float, ALIBY_RED_MAX);
     else if (op == ALIBY_RED_ADD) LAUNCH(float, float, ALIBY_RED_ADD);

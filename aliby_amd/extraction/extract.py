@@ -38,7 +38,28 @@ REDUCTION_FUNS = {"max": "max", "mean": None, "median": None, "div": "div", "add
 from aliby_amd.extraction import families  # noqa: E402
 
 
-PRODUCT_TYPES = (tuple, list)  # containers of (object, instruction) pairs the columnar pivot accepts (runner.py adds a lazy one)
+class LazyProduct:
+    """tuple(product(objects, instructions)) without materialising it (process_tree_masks' first return value)."""
+
+    def __init__(self, objects, instructions):
+        self.objects, self.instructions = objects, instructions
+
+    def __len__(self):
+        return len(self.objects) * len(self.instructions)
+
+    def __iter__(self):
+        return iter(product(self.objects, self.instructions))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(len(self))))
+        if i < 0:
+            i += len(self)
+        o, k = divmod(i, len(self.instructions))
+        return (self.objects[o], self.instructions[k])
+
+
+PRODUCT_TYPES = (tuple, list, LazyProduct)  # containers of (object, instruction) pairs the columnar pivot accepts
 
 
 def flatten(d: dict, pref=()) -> dict:
@@ -362,7 +383,8 @@ _LAYOUTS: dict = {}
 def _dense_layout(results: DeviceResults):
     """(sorted metric names, matrix column of each) for a results layout; the same for every position of a run, so it is
     worked out once.  Duplicate metric names collapse to the last writer, as the reference's dict pivot does."""
-    key = (tuple(results.instructions), tuple((s, None if k is None else len(k)) for s, k in results.blocks))
+    # the key names are part of the key: cp_measure kwargs rename columns without changing their count (texture `scale` 3 vs 5)
+    key = (tuple(results.instructions), tuple((s, None if k is None else tuple(k)) for s, k in results.blocks))
     hit = _LAYOUTS.get(key)
     if hit is None:
         names = results.column_names()

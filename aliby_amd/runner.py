@@ -27,7 +27,6 @@ from __future__ import annotations
 import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
-from itertools import product
 from pathlib import Path
 
 import numpy as np
@@ -49,9 +48,11 @@ class _Position:
 
 
 def _signature(pipeline: dict):
-    """Positions can share device steps when their pipelines have the same shape: step names in order, ntps, wiring."""
+    """Positions can share device steps when their pipelines have the same shape: step names in order, ntps, wiring, and what
+    is saved (a saved tile step takes the host path, so positions that differ in `save` do not share a batch)."""
     return (tuple(pipeline["steps"]), pipeline.get("ntps", 1), repr(sorted(pipeline.get("passed_data", {}).items())),
-            repr(sorted(pipeline.get("passed_methods", {}).items())))
+            repr(sorted(pipeline.get("passed_methods", {}).items())), tuple(sorted(pipeline.get("save") or ())),
+            pipeline.get("save_interval", 1))
 
 
 class _SharedSteps:
@@ -142,28 +143,7 @@ class _ArenaRing:
         return arena
 
 
-class _Product:
-    """tuple(product(objects, instructions)) without materialising it (process_tree_masks' first return value)."""
-
-    def __init__(self, objects, instructions):
-        self.objects, self.instructions = objects, instructions
-
-    def __len__(self):
-        return len(self.objects) * len(self.instructions)
-
-    def __iter__(self):
-        return iter(product(self.objects, self.instructions))
-
-    def __getitem__(self, i):
-        if isinstance(i, slice):
-            return tuple(self[j] for j in range(*i.indices(len(self))))
-        if i < 0:
-            i += len(self)
-        o, k = divmod(i, len(self.instructions))
-        return (self.objects[o], self.instructions[k])
-
-
-ex.PRODUCT_TYPES = (tuple, list, _Product)
+_Product = ex.LazyProduct
 
 
 class _Phase:
@@ -275,8 +255,7 @@ class BatchRunner:
             if name not in pos.state["fn"]:
                 pos.state["fn"][name] = self.shared.get(name, pos.pipeline["steps"][name], pos.state["fn"])
             tilers.append(pos.state["fn"][name])
-        wanted = batch[0].pipeline.get("save") or []
-        if name in wanted or not all(hasattr(t, "run_tp_device") for t in tilers):
+        if any(name in (pos.pipeline.get("save") or []) for pos in batch) or not all(hasattr(t, "run_tp_device") for t in tilers):
             return [pipe_core.run_step(t, tp=tp) for t in tilers]  # host path: the reference's own container types
         # monotile positions of one shape: every stack is uploaded into its slice of ONE [B,C,Z,Y,X] block, so the batch the
         # segment / extract steps see is contiguous (no gather copy) and the identity window needs no crop either
@@ -368,17 +347,21 @@ class BatchRunner:
         # The table's column order (metric names sorted) is known from the layout alone: the device hands over the rows
         # twice — as they are (per-position results, read on demand) and column-sorted + transposed, so that every Arrow
         # column of the batch table is a window of the downloaded block and the host never transposes 100+ MB per batch.
-        flat = [o for objs in every for o in objs]
-        whole = ex.DeviceResults(None, flat, instructions, blocks)
-        _, take = ex._dense_layout(whole)
-        sorted_t = matrix.index_select(1, torch.as_tensor(take, device=matrix.device)).t().contiguous() if matrix.shape[0] else matrix.t()
-        download = eng.to_host_async((matrix, sorted_t), slot=None, alloc=self._arena.alloc if self._arena is not None else None)
-        whole._matrix = _LazyRows(download, 0, 0, len(flat))
-        whole._transposed = _LazyRows(download, 1, None, None, copy=self._arena is not None)  # (the returned tables live on)
+        # (Only one-timepoint runs pivot the batch at once: a time-lapse downloads its rows once per timepoint, as they are.)
+        alloc = self._arena.alloc if self._arena is not None else None
+        if batch[0].pipeline.get("ntps", 1) == 1 and tp == 0:
+            flat = [o for objs in every for o in objs]
+            whole = ex.DeviceResults(None, flat, instructions, blocks)
+            _, take = ex._dense_layout(whole)
+            sorted_t = matrix.index_select(1, torch.as_tensor(take, device=matrix.device)).t().contiguous() if matrix.shape[0] else matrix.t()
+            download = eng.to_host_async((matrix, sorted_t), slot=None, alloc=alloc)
+            whole._matrix = _LazyRows(download, 0, 0, len(flat))
+            whole._transposed = _LazyRows(download, 1, None, None, copy=self._arena is not None)  # (the returned tables live on)
+            self._dense[name] = dict(results=whole, bounds=bounds)  # what _profiles_for_batch needs to pivot the whole batch at once
+        else:
+            download = eng.to_host_async((matrix,), slot=None, alloc=alloc)
         for objects, (lo, hi) in zip(every, bounds):
             out.append((_Product(objects, instructions), ex.DeviceResults(_LazyRows(download, 0, lo, hi), objects, instructions, blocks)))
-        if tp == 0:  # what _profiles_for_batch needs to pivot the whole batch at once
-            self._dense[name] = dict(results=whole, bounds=bounds)
         return out
 
     # --------------------------------------------------------------------------------------------------- the loop
@@ -396,9 +379,7 @@ class BatchRunner:
         import time
 
         t0 = time.perf_counter()
-        for item in (result if isinstance(result, (list, tuple)) else (result,)):
-            if isinstance(item, np.ndarray):
-                devcache.wait_ready(item)  # the batched segmenter downloads labels asynchronously
+        _wait_host(result)  # the batched segmenter downloads labels asynchronously
         fn(result, steps_dir=steps_dir, subpath=step_name, tp=tp)
         self._tick("step outputs (.npz)", t0)
 
@@ -580,8 +561,10 @@ class BatchRunner:
                 pos.state["data"].setdefault(name, [])
                 if name not in pos.state["fn"]:
                     pos.state["fn"][name] = self.shared.get(name, pos.pipeline["steps"][name], pos.state["fn"])
-                results.append(pipe_core.run_step(pos.state["fn"][name], *pos.engine._method_args(name, pos.state, tp), tp=tp,
-                                                  **pos.engine._inputs_for(name, pos.state)))
+                args, kwargs = pos.engine._method_args(name, pos.state, tp), pos.engine._inputs_for(name, pos.state)
+                _wait_host((args, kwargs))  # a step without a batched form reads its inputs on the host, now: labels the batched
+                # segmenter is still downloading must have landed (the reference hands over finished arrays, pipe_core.py:188-205)
+                results.append(pipe_core.run_step(pos.state["fn"][name], *args, tp=tp, **kwargs))
         return results
 
     def _finish(self, pos, whole=None, k=0):
@@ -672,6 +655,18 @@ class _Done:
         return self.value
 
 
+def _wait_host(item):
+    """Block until every NumPy array inside `item` (lists / tuples / dicts, nested) holds its final bytes."""
+    if isinstance(item, np.ndarray):
+        devcache.wait_ready(item)
+    elif isinstance(item, (list, tuple)):
+        for x in item:
+            _wait_host(x)
+    elif isinstance(item, dict):
+        for x in item.values():
+            _wait_host(x)
+
+
 def _cat(tensors):
     """Concatenate along axis 0; free when the pieces are consecutive views of one allocation (the batched tile step)."""
     import torch
@@ -693,13 +688,15 @@ def _cat(tensors):
 
 def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_size: int = 16, init_step_fn=None,
                   writers: int | None = None, shard: bool = True, measure: bool = False, stats: dict | None = None,
-                  writer_processes: int | bool | None = None):
+                  writer_processes: int | bool | None = None, switch_interval: float | None = 2e-4):
     """`run_pipeline_and_post` for many positions: pipelines[i] / names[i] -> profiles/<names[i]>.parquet (+ step outputs).
 
     Returns a list aligned with `pipelines`: (pyarrow.Table, {}) for the positions this rank processed, (None, None) for
     positions skipped by resume (`overwrite=False` and the parquet exists) or owned by another rank (`shard=True` under
     torch.distributed.run: positions i % world == rank, examples/01:100-104's round-robin).
-    measure=True (diagnostic): every phase runs synchronised and inline, and the return value is {phase: ms per position}."""
+    measure=True (diagnostic): every phase runs synchronised and inline, and the return value is {phase: ms per position}.
+    switch_interval: while the call runs, the interpreter's thread switch interval is lowered to this (process-wide, restored on
+    return; None leaves it alone) — see the comment at its use."""
     from aliby_amd import parallel
 
     if init_step_fn is None:
@@ -762,7 +759,8 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
         # writer threads run Python between their GIL-free stretches; with the default 5 ms switch interval the launch thread
         # can wait that long for every hand-over, which shows up as idle gaps on the device
         interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, 2e-4))
+        if switch_interval is not None:
+            sys.setswitchinterval(min(interval, switch_interval))
         nxt = None
         clock = {"wait_ingest_s": 0.0, "device_steps_s": 0.0, "drain_writers_s": 0.0}
         for b, batch in enumerate(batches):

@@ -114,15 +114,37 @@ def _make_one(job):
     return dict(pixels=f["pixels"], nuclei=f["nuclei"], dP=dP, prob=prob)
 
 
-def make_inputs(config, cfg, fov_ids, size, procs):
-    """Distinct synthetic FOVs, generated by a pool of host processes BEFORE this process touches the GPU."""
-    import multiprocessing as mp
+def under_profiler() -> bool:
+    """rocprofv3 preloads its tool library into the program it starts, and (with --pmc) that library initialises the GPU before
+    main() runs: such a process must not fork (gpurun_out/prof_r02h.log: a fork-pool child carrying the tool's signal handlers
+    was SIGTERM'd by Pool.terminate() and took the profiler down with it)."""
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH"))
+
+
+def make_inputs(config, cfg, fov_ids, size, procs, cache=None):
+    """Distinct synthetic FOVs, generated by a pool of host processes BEFORE this process touches the GPU.  `cache`: an .npz
+    the set is loaded from when it exists and written to when it does not (scripts/*.sh generate it in an unprofiled command
+    and hand it to the profiled one, which then neither forks nor spends minutes generating on one core)."""
 
     jobs = [(config, i, size, cfg["C"], cfg["Z"], cfg["n_target"]) for i in fov_ids]
+    keys = ("pixels", "nuclei", "dP", "prob")
+    if cache and os.path.exists(cache):
+        with np.load(cache) as z:
+            if list(z["jobs"].tolist()) == [list(map(lambda v: -1 if v is None else v, j)) for j in jobs]:
+                return [{k: z[f"{k}_{i}"] for k in keys} for i in range(len(jobs))]
+    out = _make_inputs(jobs, 1 if under_profiler() else procs)
+    if cache:
+        np.savez(cache, jobs=np.array([[-1 if v is None else v for v in j] for j in jobs]),
+                 **{f"{k}_{i}": o[k] for i, o in enumerate(out) for k in keys})
+    return out
+
+
+def _make_inputs(jobs, procs):
+    import multiprocessing as mp
+
     if procs <= 1 or len(jobs) <= 1:
         return [_make_one(j) for j in jobs]
-    # close + join, not the context manager's terminate(): SIGTERM in a worker that inherited rocprofv3's preloaded tool runs the
-    # tool's signal handler there, and the profiled run then hangs now and then (seen twice under `rocprofv3 -- python3 bench.py`)
+    # close + join, not the context manager's terminate() (see under_profiler)
     pool = mp.get_context("fork").Pool(min(procs, len(jobs)))
     try:
         return pool.map(_make_one, jobs, chunksize=1)
@@ -131,9 +153,78 @@ def make_inputs(config, cfg, fov_ids, size, procs):
         pool.join()
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain environment (no RANK): start N rank processes — one per GPU, this same file under
+    torch.distributed.run, rendezvous on 127.0.0.1 — wait for them and relay rank 0's JSON line.  This parent never touches the
+    GPU (no torch.cuda, no libaliby_hip.so): the ranks are fresh children, nothing that has initialised HIP is exec'ed or forked.
+    Each rank gets an equal share of the host cores this process may use (ALIBY_HOST_CORES)."""
+    import socket
+    import subprocess
+
+    from aliby_amd import hostinfo
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("ALIBY_HOST_CORES", str(max(1, hostinfo.usable_cores(default_cap=16 * n) // n)))
+    env.setdefault("OMP_NUM_THREADS", env["ALIBY_HOST_CORES"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:  # rank 0 prints the one JSON line; anything else a rank writes to stdout is passed through to stderr
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {n}-rank job failed (exit code {rc}, JSON line {'missing' if line is None else 'present'})\n")
+        sys.exit(rc or 1)
+    print(line)
+    sys.exit(0)
+
+
+def rehearse(args):
+    """`--rehearse`: the N>1 control flow without any device work — rendezvous, barrier, max-over-ranks timing, the final gather
+    of stand-in rows — so that the launcher and the collectives can be tested on a machine without a GPU (gloo).  The line it
+    prints has `value: null`: it is not a measurement."""
+    import torch
+
+    from aliby_amd import parallel
+
+    rank, world, _ = parallel.rank_world()
+    backend = os.environ.get("ALIBY_DIST_BACKEND", "nccl")
+    parallel.init(backend if world > 1 else None)
+    dist = torch.distributed if world > 1 else None
+    parallel.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    parallel.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n = 3 + rank
+    vals = torch.full((n, 4), float(rank), dtype=torch.float64)
+    meta = torch.tensor([[i * world + rank, i, 0, 0] for i in range(n)], dtype=torch.int64)
+    gv, _ = parallel.gather_rows(vals, meta)
+    if rank == 0:
+        print(json.dumps({"metric": "FOV tiles/sec (whole node)", "value": None, "unit": "tiles/s", "n_gpus": world, "ranks": world,
+                          "backend": (dist.get_backend() if dist is not None else None), "steps": 0, "warmup": 0,
+                          "ms_per_step": round(1e3 * float(t.item()), 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "data": "none (--rehearse: launcher + collectives only, no device work)",
+                          "config": {"workload": "rehearsal", "gathered_rows": int(gv.shape[0]),
+                                     "host_cores_per_rank": int(os.environ.get("ALIBY_HOST_CORES", 0))}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU).  Under torch.distributed.run (RANK set) it must equal "
+                    "WORLD_SIZE; from a plain environment with N > 1 this process starts the N ranks itself and relays rank 0's line")
+    ap.add_argument("--rehearse", action="store_true", help="launcher + collectives only, no device work (CPU test of the N>1 path)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (1-based)")
@@ -142,7 +233,10 @@ def main():
     ap.add_argument("--total-fovs", type=int, default=0, help="strong-scaling mode: this many FOVs in all, split over the ranks "
                     "(steps = ceil(total / (gpus * fovs)); --steps is then ignored)")
     ap.add_argument("--size", type=int, default=0, help="override the configuration's frame size")
-    ap.add_argument("--net-dtype", default="bfloat16", choices=["bfloat16", "float32", "float16"])
+    ap.add_argument("--net-dtype", default="bfloat16", choices=["bfloat16", "float32", "float16"],
+                    help="bfloat16 (default, the product path): the hand-written MFMA network of libaliby_hip.so.  float32 / float16: the "
+                    "plain torch module through MIOpen — an A/B reference for the network's numerics, NOT the product path; the line "
+                    "then says so in mfma.path and carries no conv roofline")
     ap.add_argument("--net-batch", type=int, default=288, help="224x224 tiles per U-Net forward (the reference's batch_size knob)")
     ap.add_argument("--time-every", type=int, default=7, help="bracket every n-th launch of the per-layer network kernels with HIP "
                     "events (they are launched ~600 times per step; 1 = every launch)")
@@ -153,8 +247,19 @@ def main():
     ap.add_argument("--api-fovs", type=int, default=0, help="positions of the API leg (default: 8 batches of --fovs)")
     ap.add_argument("--overlap", action="store_true", help="experiment: dynamics + features of step k on a second stream while the "
                     "network of step k+1 runs (software pipelining across steps)")
+    ap.add_argument("--inputs", default="", help="path prefix of an input cache (<prefix>.r<rank>of<world>.npz): loaded when present, "
+                    "written when not; profiled runs load what an earlier, unprofiled command generated")
+    ap.add_argument("--inputs-only", action="store_true", help="generate (and cache) the synthetic inputs, then exit: no GPU work")
     ap.add_argument("--host-procs", type=int, default=0, help="host processes for input generation / the CPU baseline (default: all)")
     args = ap.parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', 1)}: start one rank per GPU "
+                 f"(torch.distributed.run --nproc-per-node {args.gpus}), or run `python bench.py --gpus {args.gpus}` from a plain "
+                 "environment and let it start the ranks")
+    if args.rehearse:
+        return rehearse(args)
     if args.config == 4:
         return main_timelapse(args)
     cfg = CONFIGS[args.config]
@@ -168,7 +273,10 @@ def main():
     procs = args.host_procs or hostinfo.usable_cores()  # this rank's share of the host, not os.cpu_count()
     # ---- everything that forks happens before the GPU is touched: synthetic inputs, then the CPU baseline ---------------
     distinct = max(1, min(args.distinct, args.fovs))
-    base = make_inputs(args.config, cfg, [rank + world * i for i in range(distinct)], size, procs)
+    base = make_inputs(args.config, cfg, [rank + world * i for i in range(distinct)], size, procs,
+                       cache=(args.inputs and f"{args.inputs}.r{rank}of{world}.npz"))
+    if args.inputs_only:
+        return
     channels = list(range(cfg["C"])) if cfg["channels"] is None else list(cfg["channels"])
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -391,7 +499,8 @@ def main():
                                                                        "first_conv", "conv1x1_mfma", "style")) / max(steps, 1)
     net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
     mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,
-            "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3}
+            "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3,
+            "path": "hand-written HIP (libaliby_hip.so)" if model.fused is not None else "torch module (MIOpen) - A/B reference, not the product path"}
 
     # ---- the same workload through the step API ------------------------------------------------------------------
     api = None
@@ -408,6 +517,8 @@ def main():
             "value": round(tiles_per_s, 3),
             "unit": "tiles/s",
             "n_gpus": world,
+            "ranks": world,
+            "backend": (dist.get_backend() if dist is not None else None),
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / steps, 3),
@@ -671,7 +782,8 @@ def main_timelapse(args):
                     "note": "117-px tiles: a launch moves ~10 MB, so every kernel of this configuration is launch-latency bound"}
     if rank == 0:
         print(json.dumps({
-            "metric": "FOV tiles/sec (whole node)", "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": K,
+            "metric": "FOV tiles/sec (whole node)", "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "ranks": world,
+            "backend": (dist.get_backend() if dist is not None else None), "steps": K,
             "warmup": W, "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"u16 pixels, f64 feature accumulators, f32 dynamics, {args.net_dtype} U-Net", "data": "synthetic",
             "config": {"workload": f"C4: {B} time-lapse positions/GPU in lockstep, T={K} timed timepoints of [1,5,512,512], {n_tiles} trap tiles "

@@ -39,7 +39,8 @@ enum {
   ALIBY_ERR_UNSUPPORTED = 5   /* e.g. non-ufunc reducer   -> Exception     */
 };
 
-enum { ALIBY_U16 = 0, ALIBY_F32 = 1 };
+enum { ALIBY_U16 = 0, ALIBY_F32 = 1,
+       ALIBY_U64 = 2, ALIBY_F64 = 3 /* output dtypes of aliby_reduce_z only: NumPy's own result types */ };
 
 /* reduce_z operators — extraction/core/functions/loaders.py:110-127 ("max","add","div";
  * "mean"/"median" are not ufuncs and raise in distributors.py:20-24). */
@@ -89,8 +90,11 @@ int aliby_crop_pad_u16(aliby_ctx* ctx, const uint16_t* stack, int C, int Z, int 
 /* ---- a5: reduce_z ------------------------------------------------------- */
 /* reduce_z(pixels, ufunc, axis) (extraction/core/functions/distributors.py:6-24):
  * in [dev] is [outer, Z, inner]; out [dev] is [outer, inner]; ufunc.reduce order
- * (left fold over Z).  dtype preserved for max/add (u16 add wraps like numpy);
- * div on u16 yields f32 per numpy true-divide semantics narrowed to f32. */
+ * (left fold over Z).  max keeps the input dtype.  For u16 input NumPy's results are
+ * uint64 for add.reduce (small unsigned ints are promoted, no wrap) and float64 for
+ * divide.reduce: out_dtype ALIBY_U64 / ALIBY_F64 give exactly those; out_dtype
+ * ALIBY_F32 gives the same values narrowed to f32, which is what the feature kernels
+ * consume (sums exact while < 2^24, i.e. Z <= 256).  f32 input: f32 left fold. */
 int aliby_reduce_z(aliby_ctx* ctx, const void* in, int dtype, size_t outer, int Z, size_t inner,
                    int op, void* out, int out_dtype, void* stream);
 

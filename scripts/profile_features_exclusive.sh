@@ -4,7 +4,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r02x}
 export ALIBY_FEATURE_STREAMS=1
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-api > gpurun_out/prof_${TAG}.log 2>&1
+# inputs are generated (fork pool) by an UNPROFILED command; the profiled ones load them and never fork
+timeout -k 10 300 python3 bench.py --inputs-only --inputs /tmp/aliby_inputs && \
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-api --inputs /tmp/aliby_inputs > gpurun_out/prof_${TAG}.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/prof_${TAG}/**/*kernel_trace.csv", recursive=True)[0]

@@ -4,6 +4,7 @@ exporting every symbol include/aliby_hip.h declares, and the world_size-2 gloo p
 """
 
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -422,3 +423,49 @@ def test_run_positions_shards_over_ranks_world_size_2_gloo(tmp_path):
     )
     assert out.returncode == 0, out.stdout + out.stderr
     assert "RUNNER_OK" in out.stdout
+
+
+# ---------------------------------------------------------------------------------- bench.py starts its own ranks
+def test_bench_gpus_flag_starts_the_ranks_itself_gloo():
+    """`python bench.py --gpus 2` from a plain environment (no RANK / WORLD_SIZE) is a 2-rank job: the parent starts the ranks
+    under torch.distributed.run and relays rank 0's line.  --rehearse keeps the device work out, so the
+    launcher, the rendezvous, the max-over-ranks timing and the final gather run here without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.pop("ALIBY_HOST_CORES", None)
+    env["ALIBY_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rehearse"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["gathered_rows"] == 3 + 4  # rank 0 brought 3 rows, rank 1 brought 4
+    assert line["config"]["host_cores_per_rank"] >= 1
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_world_size():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--rehearse"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_dense_layout_cache_keeps_renamed_columns_apart():
+    """Two extractions in one process whose cp_measure kwargs rename columns without changing their count (texture scale 3 vs 5)
+    must not share a cached table layout."""
+    from aliby_amd.extraction import extract as ex
+    from aliby_amd.extraction.features import texture_names
+
+    inst = [(0, "max", "texture")]
+    objects = [(0, 1), (0, 2)]
+    tables = []
+    for scale in (3, 5):
+        names = texture_names(scale)
+        matrix = np.arange(2 * len(names), dtype=np.float64).reshape(2, -1) + scale
+        res = ex.DeviceResults(matrix, objects, inst, [(0, names)])
+        tables.append(ex.format_extraction((ex._Dense, res)))
+    c3, c5 = (set(t.column_names) - {"tile", "label"} for t in tables)
+    assert c3.isdisjoint(c5), sorted(c3 & c5)[:3]
+    assert all("_3_" in c for c in c3) and all("_5_" in c for c in c5)
+    assert tables[1]["0/max/texture/" + texture_names(5)[0]].to_pylist() == [5.0, 5.0 + len(texture_names(5))]

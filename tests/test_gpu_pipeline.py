@@ -99,6 +99,19 @@ def test_reduce_z(engine, op, name):
         assert np.allclose(got, want.astype(np.float64), rtol=1e-6)
     with pytest.raises(Exception):
         _lib.check(engine.lib.aliby_reduce_z(engine.ctx.handle, _ptr(dev), _lib.U16, 12, 5, 33 * 47, 7, _ptr(out), out_dt, _stream_ptr()))
+    # the host-facing reduce_z (distributors.py:6-24) hands back NumPy's own result dtype and bits: uint16 / uint64 / float64
+    from aliby_amd.extraction.functions import reduce_z
+
+    for axis in (0, 1):
+        got = reduce_z(a[0], ufunc, axis=axis)  # [C,Z,Y,X] reduced over C or over Z
+        want = ufunc.reduce(a[0], axis=axis)
+        assert got.dtype == want.dtype and np.array_equal(got, want), (name, axis, got.dtype, want.dtype)
+    f = rng.random((4, 21, 17), dtype=np.float32) + 0.5
+    got = reduce_z(f, ufunc)
+    assert got.dtype == np.float32 and np.array_equal(got, ufunc.reduce(f, axis=0))
+    assert reduce_z(f[0], ufunc) is not None and reduce_z(f[0], ufunc).shape == (21, 17)
+    with pytest.raises(Exception, match="invalid reducer"):
+        reduce_z(a[0], np.mean)
 
 
 def test_relabel_sequential(engine):
