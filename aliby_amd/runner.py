@@ -373,7 +373,10 @@ class BatchRunner:
                 with self._timed("write: step outputs (.npz, zlib)"):
                     dispatch_write_fn(step_name)(result, steps_dir=pos.steps_dir, subpath=step_name, tp=tp)  # (_timed drained the device)
                 return
-            pos.pending.append(self.pool.submit(self._write_step, dispatch_write_fn(step_name), result, pos.steps_dir, step_name, tp))
+            # (a dict result is written as it is NOW: the engine drops the tile step's "pixels" at the end of the timepoint,
+            # pipe_core.py:238-242, while the writer thread may still be serialising it)
+            snap = dict(result) if isinstance(result, dict) else result
+            pos.pending.append(self.pool.submit(self._write_step, dispatch_write_fn(step_name), snap, pos.steps_dir, step_name, tp))
 
     def _write_step(self, fn, result, steps_dir, step_name, tp):
         import time
