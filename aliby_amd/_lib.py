@@ -40,6 +40,17 @@ class aliby_object(C.Structure):
     ]
 
 
+class aliby_pq_column(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("reserved", C.c_int32)]
+
+
+class aliby_npy_member(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("descr", C.c_char_p), ("shape", C.POINTER(C.c_int64)), ("data", C.c_void_p),
+                ("ndim", C.c_int32), ("itemsize", C.c_int32)]
+
+
+PQ_F64, PQ_I64, PQ_U16, PQ_STR = range(4)
+
 OBJECT_DTYPE = np.dtype(
     [("tile", "<i4"), ("label", "<i4"), ("y0", "<i4"), ("x0", "<i4"), ("y1", "<i4"), ("x1", "<i4"),
      ("area", "<i4"), ("pad_", "<i4")]
@@ -123,6 +134,9 @@ _SIGNATURES = {
     "aliby_features_cell": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_coloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i,
                                   C.c_double, C.c_double, _vp, _vp, _vp]),
+    "aliby_parquet_write": (_i, [C.c_char_p, _vp, _i, _vp, _i, _vp, _vp, _i]),
+    "aliby_npz_write": (_i, [C.c_char_p, _vp, _i, _i]),
+    "aliby_host_codecs": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "aliby_object_ranks": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
 }
 
@@ -157,6 +171,25 @@ def load() -> C.CDLL:
         raise AlibyHipError("libaliby_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+_fast = None
+
+
+def load_fast() -> C.PyDLL:
+    """The same library through ctypes.PyDLL: calls keep the interpreter lock.  For the short, asynchronous launch functions
+    of the network (~600 calls per 64-position batch): a CDLL call drops the lock and must win it back from the writer threads
+    every time, which showed up as idle gaps on the device.  Never use it for a call that blocks (stream waits, file writes)."""
+    global _fast
+    if _fast is None:
+        load()
+        lib = C.PyDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _fast = lib
+    return _fast
 
 
 def check(rc: int) -> None:

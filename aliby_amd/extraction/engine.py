@@ -217,6 +217,9 @@ class FeatureEngine:
         F, Y, X = labels.shape
         lib, h = self.lib, self.ctx.handle
         mx = np.zeros(F, np.int32)
+        from aliby_amd import trace
+
+        trace.mark("object_table:call")
         with self.timed("object_table"):
             _lib.check(lib.aliby_label_max(h, _ptr(labels), F, Y, X, _ptr(mx), _stream_ptr()))
         offsets = np.zeros(F + 1, np.int32)
@@ -236,6 +239,7 @@ class FeatureEngine:
             max_area, max_h, max_w = int(host["area"].max()), int(hh.max()), int(ww.max())
         else:
             max_area = max_h = max_w = 0
+        trace.mark("object_table:returned")
         return ObjectTable(dev, host, offsets, n_obj, max_area, max_h, max_w)
 
     def track_stitch(self, prev: torch.Tensor, cur: torch.Tensor, prev_table: ObjectTable, cur_table: ObjectTable,

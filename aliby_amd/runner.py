@@ -32,9 +32,9 @@ from pathlib import Path
 import numpy as np
 import pyarrow.parquet
 
-from aliby_amd import devcache, pipe_core
+from aliby_amd import devcache, pipe_core, trace
 from aliby_amd.extraction import extract as ex
-from aliby_amd.io.write import dispatch_write_fn, write_profiles
+from aliby_amd.io.write import _same_columns, dispatch_write_fn, table_layout, write_parquet_native, write_profiles
 
 
 class _Position:
@@ -126,6 +126,7 @@ class _Arena:
 
 class _ArenaRing:
     def __init__(self, n=3):
+        self.n = n
         self.lock = threading.Condition()
         self.free = [_Arena(self) for _ in range(n)]
         self.waited = 0.0
@@ -141,6 +142,31 @@ class _ArenaRing:
         self.waited += time.perf_counter() - t0  # back-pressure: the launch thread was ahead of the writers by n batches
         arena.left = positions
         return arena
+
+
+_RINGS: dict = {}
+
+
+def _shared_ring():
+    """The page-locked arenas outlive a run_positions call: hipHostMalloc of ~400 MB takes tens of ms on the launch thread, and
+    a job of a few batches would pay it three times per call.  One ring per (process, device); `release_pinned()` frees them."""
+    key = None
+    try:
+        import torch
+
+        key = torch.cuda.current_device() if torch.cuda.is_available() else None
+    except ImportError:
+        pass
+    ring = _RINGS.get(key)
+    if ring is None or len(ring.free) != ring.n:  # (a ring with arenas still out belongs to a run that failed: start afresh)
+        ring = _RINGS[key] = _ArenaRing(3)
+    ring.waited = 0.0
+    return ring
+
+
+def release_pinned():
+    """Give back the page-locked memory `run_positions` keeps between calls."""
+    _RINGS.clear()
 
 
 _Product = ex.LazyProduct
@@ -232,8 +258,11 @@ class BatchRunner:
         self._tables = {}
         self._dense = {}  # extract step -> whole-batch results of the batch in flight
         self._h2d_stream = None
-        self._ring = _ArenaRing(3)
+        self._ring = _shared_ring()
         self._arena = None  # of the batch the launch thread is working on
+        self._submits = []  # writer tasks not handed over yet (see _queue)
+        self._defer = os.environ.get("ALIBY_DEFER_SUBMITS", "1") != "0"
+        trace.BEFORE_BLOCK.append(self.flush_submits)
 
     def _tick(self, what, t0):
         import time
@@ -293,6 +322,7 @@ class BatchRunner:
                 blocks.append(getattr(tiler, method)(tp))
         if not all(f is fns[0] for f in fns) or not hasattr(fns[0], "batch"):
             return None
+        trace.mark("segment:blocks ready")
         return fns[0].batch(blocks, pinned_alloc=self._arena.alloc if self._arena is not None else None)
 
     # --------------------------------------------------------------------------------------------- extract steps
@@ -376,7 +406,43 @@ class BatchRunner:
             # (a dict result is written as it is NOW: the engine drops the tile step's "pixels" at the end of the timepoint,
             # pipe_core.py:238-242, while the writer thread may still be serialising it)
             snap = dict(result) if isinstance(result, dict) else result
-            pos.pending.append(self.pool.submit(self._write_step, dispatch_write_fn(step_name), snap, pos.steps_dir, step_name, tp))
+            self._queue(self.pool, pos.pending, self._write_step, dispatch_write_fn(step_name), snap, pos.steps_dir, step_name, tp)
+
+    def _queue(self, pool, sink, fn, *args):
+        """pool.submit(fn, *args), later: tasks for the writer threads are handed over in bursts of a whole batch, and every
+        woken thread starts with Python (paths, ctypes structures, table slices) that competes with the launch thread for the
+        interpreter lock — measured as 13 ms between the segmenter's last synchronisation and the first feature kernel of a
+        64-position batch.  So they wait in `_submits` until the launch thread is about to sleep in the next long device wait
+        (trace.about_to_block, called by the dynamics) or the run ends.  Returns a Future that mirrors the real one."""
+        from concurrent.futures import Future
+
+        if self.measure is not None or not self._defer:
+            fut = pool.submit(fn, *args)
+            if sink is not None:
+                sink.append(fut)
+            return fut
+        proxy = Future()
+
+        def go():
+            def done(real):
+                exc = real.exception()
+                if exc is not None:
+                    proxy.set_exception(exc)
+                else:
+                    proxy.set_result(real.result())
+
+            pool.submit(fn, *args).add_done_callback(done)
+
+        self._submits.append(go)
+        if sink is not None:
+            sink.append(proxy)
+        return proxy
+
+    def flush_submits(self):
+        self._flushed = True
+        todo, self._submits = self._submits, []
+        for go in todo:
+            go()
 
     def _write_step(self, fn, result, steps_dir, step_name, tp):
         import time
@@ -390,6 +456,7 @@ class BatchRunner:
         """States of a batch and the first timepoint of its leading tile step, on the caller's thread: run_positions calls this
         for batch k+1 on the ingest thread while batch k computes; uploads go to a side stream, `ready` marks their end."""
         steps = batch[0].pipeline["steps"]
+        trace.mark("prepare:begin (ingest thread)")
         for pos in batch:
             pos.engine = pipe_core.Engine(pos.pipeline, pos.steps_dir, self.shared.get)
             pos.state = pos.engine.fresh_state(steps)
@@ -414,6 +481,7 @@ class BatchRunner:
                 ready = torch.cuda.Event()
                 ready.record(self._h2d_stream)
         batch[0].prefetched = (first, results, ready)
+        trace.mark("prepare:end (ingest thread)")
 
     def run_batch(self, batch):
         """All timepoints of a batch of positions with one signature.  Returns one future per position -> (profiles, {})."""
@@ -426,14 +494,18 @@ class BatchRunner:
         pre, batch[0].prefetched = getattr(batch[0], "prefetched", None), None
         self._dense = {}
         arena = None
+        self._flushed = False
         try:
             import torch
 
             if torch.cuda.is_available():
+                if not self._ring.free:
+                    self.flush_submits()  # (the tasks that will free an arena must be running before we wait for one)
                 arena = self._ring.acquire(len(batch))  # blocks while three batches are still being written: back-pressure
         except ImportError:
             pass
         self._arena = arena
+        trace.mark("run_batch:arena acquired")
         for pos in batch:
             pos.arena = arena
         for tp in range(ntps):
@@ -443,26 +515,32 @@ class BatchRunner:
                 phase = ("tile: ingest + H2D" if name.startswith("tile") else "segment: project + normalise + network + dynamics + labels D2H"
                          if name.startswith("segment") else "extract: object table + feature kernels + rows D2H"
                          if name.startswith("extract") else f"step {name}")
+                trace.mark(f"{name}:begin")
                 with self._timed(phase) if not (tp == 0 and pre is not None and pre[0] == name) else contextlib.nullcontext():
                     results = self._run_step_batched(batch, name, tp, pre)
+                trace.mark(f"{name}:returned")
                 for pos, result in zip(batch, results):
                     pos.state["data"].setdefault(name, [])
-                    self._save(pos, name, result, tp)
                     pos.state["data"][name].append(result)
                     pos.state["tps"][name] = tp + 1
+                for pos, result in zip(batch, results):
+                    self._save(pos, name, result, tp)  # (queued: see _queue)
             for pos in batch:
                 pos.engine._end_of_timepoint(pos.state)
+        trace.mark("batch:steps done")
         dense, self._dense = self._dense, {}
         names = [n for n in steps if n.startswith("extract") or n.startswith("nahual_embed")]
         whole = None
         if ntps == 1 and names and all(n in dense for n in names):
             whole = _Once(lambda: self._profiles_for_batch(batch, names, dense))  # one pivot + join for the batch, on a writer thread
+        if not self._flushed:
+            self.flush_submits()  # no long device wait in this batch's steps (no segmenter): nothing to hide the hand-over behind
         if self.measure is not None:
             return [_Done(self._finish(pos, whole, k)) for k, pos in enumerate(batch)]
-        if whole is not None and self.proxies is not None:
-            self.pool.submit(self._warm, whole)  # pivot + IPC export start on a writer thread right away
-            return [self.proxies.submit(self._finish, pos, whole, k) for k, pos in enumerate(batch)]
-        return [self.pool.submit(self._finish, pos, whole, k) for k, pos in enumerate(batch)]
+        if whole is not None and self.proxies is not None and self.writer_processes:
+            self._queue(self.pool, None, self._warm, whole)  # pivot + IPC export start on a writer thread right away
+            return [self._queue(self.proxies, None, self._finish, pos, whole, k) for k, pos in enumerate(batch)]
+        return [self._queue(self.pool, None, self._finish, pos, whole, k) for k, pos in enumerate(batch)]
 
     @staticmethod
     def _warm(whole):
@@ -496,7 +574,14 @@ class BatchRunner:
                 joined.append((table, dense[members[0]]["bounds"]))
             n = len(batch)
             ipc = _Once(lambda: self._export_ipc(joined, n)) if self.writer_processes else None
-            return joined, ipc
+            # where every column of the batch tables lives (address of row 0, item width): a position's file is then encoded
+            # natively from row windows of these buffers, on a writer thread with the interpreter lock released
+            layouts = None
+            if not self.writer_processes and os.environ.get("ALIBY_NATIVE_WRITERS", "1") != "0":
+                layouts = [table_layout(t) for t, _ in joined]
+                if any(lay is None for lay in layouts) or any(not _same_columns(t.schema, joined[0][0].schema) for t, _ in joined[1:]):
+                    layouts = None
+            return joined, ipc, layouts
 
     def _export_ipc(self, joined, n_positions):
         """The batch's tables as ONE Arrow IPC stream in /dev/shm for the writer processes; -> (path, row offset of each table)."""
@@ -584,13 +669,21 @@ class BatchRunner:
         t0 = time.perf_counter()
         got = whole.get() if whole is not None else None
         self._tick("batch pivot (one thread works, the others wait)", t0)
-        joined, ipc = got if got is not None else (None, None)
+        joined, ipc, layouts = got if got is not None else (None, None, None)
         written = False
         if joined is not None:
             import pyarrow as pa
 
             parts = [t.slice(b[k][0], b[k][1] - b[k][0]) for t, b in joined if b[k][1] > b[k][0]]
             profiles = pa.concat_tables(parts) if parts else pipe_core._empty_profiles()
+            if layouts is not None and parts:
+                t0 = time.perf_counter()
+                with self._timed("write: parquet (zstd)"):
+                    pos.profiles_file.parent.mkdir(parents=True, exist_ok=True)
+                    write_parquet_native(pos.profiles_file, [(lay, b[k][0], b[k][1] - b[k][0]) for lay, (t, b) in zip(layouts, joined)
+                                                             if b[k][1] > b[k][0]])
+                self._tick("parquet, native encoder on this thread", t0)
+                written = True
             t0 = time.perf_counter()
             ipc = ipc.get() if ipc is not None else None
             self._tick("IPC export to /dev/shm (one thread works, the others wait)", t0)
@@ -622,6 +715,9 @@ class BatchRunner:
         return profiles, {}
 
     def close(self):
+        self.flush_submits()
+        if self.flush_submits in trace.BEFORE_BLOCK:
+            trace.BEFORE_BLOCK.remove(self.flush_submits)
         if self.proxies is not None:
             self.proxies.shutdown(wait=True)
         self.pool.shutdown(wait=True)
@@ -733,8 +829,11 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
         # each).  Half the share each for the parquet processes and the writer threads (.npz compression, pivot, IPC export):
         # measured on the 16-core share of a one-GPU box, (threads, processes) = (4, 12) 264, (6, 10) 274, (8, 8) 314,
         # (10, 6) 245 positions/s (scripts/api_sweep.sh)
+        # (round 3: the native encoders run on the writer threads with the interpreter lock released, which beats the processes —
+        # they stay available for tables the native encoder does not cover: ALIBY_WRITER_PROCS=n or writer_processes=n)
         big = writer_processes is True or (len(todo) >= 4 * batch_size and not measure)
-        writer_processes = int(os.environ.get("ALIBY_WRITER_PROCS", max(1, cores // 2))) if big else 0
+        default_procs = max(1, cores // 2) if os.environ.get("ALIBY_NATIVE_WRITERS", "1") == "0" else 0
+        writer_processes = int(os.environ.get("ALIBY_WRITER_PROCS", default_procs)) if big else 0
     if measure:
         writer_processes = 0
     if writers is None:
@@ -762,6 +861,8 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
         # writer threads run Python between their GIL-free stretches; with the default 5 ms switch interval the launch thread
         # can wait that long for every hand-over, which shows up as idle gaps on the device
         interval = sys.getswitchinterval()
+        if os.environ.get("ALIBY_SWITCH_INTERVAL"):
+            switch_interval = float(os.environ["ALIBY_SWITCH_INTERVAL"])
         if switch_interval is not None:
             sys.setswitchinterval(min(interval, switch_interval))
         nxt = None
@@ -781,11 +882,15 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
             t2 = time.perf_counter()
             clock["wait_ingest_s"] += t1 - t0
             clock["device_steps_s"] += t2 - t1
+        runner.flush_submits()
         t0 = time.perf_counter()
         for pos, fut in futures:
             out[pos.index] = fut.result()
         clock["drain_writers_s"] = time.perf_counter() - t0
         if stats is not None:
+            if trace.MARKS is not None:
+                stats["trace"] = [(lab, round(t, 5)) for lab, t in trace.MARKS]
+                trace.MARKS.clear()
             clock["of_which_waiting_for_a_free_arena_s"] = runner._ring.waited
             stats.update({k: round(v, 4) for k, v in clock.items()}, batches=len(batches), writers=writers,
                          writer_processes=int(runner.writer_processes),

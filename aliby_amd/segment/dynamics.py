@@ -16,6 +16,12 @@ from aliby_amd.extraction.engine import _ptr, _stream_ptr
 _workspaces: dict = {}
 
 
+def _mark(label):
+    from aliby_amd import trace  # (diagnostic marks of the launch thread: ALIBY_RUNNER_TRACE)
+
+    trace.mark(label)
+
+
 def _workspace(lib, F, Y, X, device):
     need = int(lib.aliby_masks_workspace_bytes(F, Y, X))
     key = (str(device),)
@@ -38,6 +44,10 @@ def masks_from_flows(eng, dP, cellprob, niter=200, cellprob_threshold=0.0, flow_
     n = np.zeros(max(F, 1), np.int32)
     ws, need = _workspace(eng.lib, F, Y, X, dP.device)
     pf = torch.zeros((F, 2, Y, X), dtype=torch.float32, device=dP.device) if return_endpoints else None
+    _mark("dynamics:call")
+    from aliby_amd import trace
+
+    trace.about_to_block()  # (the call below waits for everything queued so far: ~100 ms for a 64-position batch)
     with eng.timed("dynamics"):
         _lib.check(
             eng.lib.aliby_masks_from_flows(
@@ -46,6 +56,7 @@ def masks_from_flows(eng, dP, cellprob, niter=200, cellprob_threshold=0.0, flow_
                 _ptr(ws), need, _ptr(labels), _ptr(n), _ptr(pf) if pf is not None else 0, _stream_ptr(),
             )
         )
+    _mark("dynamics:returned")
     if return_endpoints:
         return labels, n[:F], pf
     return labels, n[:F]

@@ -86,7 +86,8 @@ class FusedUNet:
         # deep levels (128 / 256 channels): one K-loop launch per convolution (csrc/nn_conv_deep.hip); 0 = the K/N-slice launches
         self.deep_kernel = os.environ.get("ALIBY_CONV_DEEP", "1") != "0"
         self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
-        self.lib, self.h = eng.lib, eng.ctx.handle
+        # every call made through self.lib is an asynchronous kernel launch: they keep the interpreter lock (see _lib.load_fast)
+        self.lib, self.h = (_lib.load_fast() if os.environ.get("ALIBY_FAST_LAUNCH", "1") != "0" else eng.lib), eng.ctx.handle
         net = net.float().eval()
         self.down = []
         for i, blk in enumerate(net.down):

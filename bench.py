@@ -600,8 +600,10 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            names = [f"w{rank}_{i:05d}" for i in range(B)]
-            runner.run_positions(pipelines(B), names, out_dir / "warm", batch_size=B, shard=False, writers=WRITERS)  # warm-up: one batch
+            # warm-up: three batches — the runner keeps three page-locked arenas and three [B,C,Z,Y,X] device blocks in flight, and
+            # each is allocated (hipHostMalloc / hipMalloc of ~0.5 GB, tens of ms on the launch thread) the first time it is used
+            names = [f"w{rank}_{i:05d}" for i in range(3 * B)]
+            runner.run_positions(pipelines(3 * B), names, out_dir / "warm", batch_size=B, shard=False, writers=WRITERS)
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()

@@ -474,6 +474,37 @@ int aliby_trap_match_template(aliby_ctx* ctx, const double* padded, int PH, int 
 int aliby_trap_maxfilter1d(aliby_ctx* ctx, const double* in, double* out, int H, int W, int axis, int radius,
                            void* stream);
 
+/* ---- a17: the step API's files, encoded natively (host code, no GPU work) ------------------ */
+/* profiles/<name>.parquet — pyarrow.parquet.write_table(profiles, path, compression="zstd")
+ * (src/aliby/pipe_core.py:412-413).  One row group, one PLAIN data page per column, fields OPTIONAL with every value
+ * present, zstd level `zstd_level` (negative levels are zstd's fast modes; ALIBY_PQ_UNCOMPRESSED: no compression) through
+ * libzstd.so.1 (dlopen).  A column's rows come as n_segs
+ * segments (a position's table is the concatenation of one slice per object set): values[c * n_segs + s] points at
+ * seg_rows[s] items — double / int64 / uint16, or for ALIBY_PQ_STR the Arrow utf8 layout: int32 offsets[seg_rows[s] + 1]
+ * with the characters at aux[c * n_segs + s].  Thread-safe (one compression context per calling thread). */
+enum { ALIBY_PQ_F64 = 0, ALIBY_PQ_I64 = 1, ALIBY_PQ_U16 = 2, ALIBY_PQ_STR = 3 };
+#define ALIBY_PQ_UNCOMPRESSED (-1000000)
+typedef struct aliby_pq_column {
+  const char* name; /* UTF-8, NUL-terminated */
+  int32_t type;     /* ALIBY_PQ_* */
+  int32_t reserved;
+} aliby_pq_column;
+int aliby_parquet_write(const char* path, const aliby_pq_column* cols, int n_cols, const int64_t* seg_rows, int n_segs,
+                        const void* const* values, const void* const* aux, int zstd_level);
+/* steps/<name>/<step>/<tp:04d>.npz — numpy.savez_compressed(out_file, labels) (src/aliby/io/write.py:25-51): a zip
+ * archive of deflated .npy members (version 1.0 headers, C order).  libdeflate.so.0 (dlopen) when present, zlib otherwise. */
+typedef struct aliby_npy_member {
+  const char* name;     /* "arr_0", "tile_3", ... (".npy" is appended) */
+  const char* descr;    /* NumPy dtype string, e.g. "<u2" */
+  const int64_t* shape; /* [ndim] */
+  const void* data;     /* C-contiguous */
+  int32_t ndim;
+  int32_t itemsize;     /* bytes per element */
+} aliby_npy_member;
+int aliby_npz_write(const char* path, const aliby_npy_member* members, int n_members, int level);
+/* which of the two optional codec libraries were found on this machine */
+int aliby_host_codecs(int* have_zstd, int* have_libdeflate);
+
 #ifdef __cplusplus
 }
 #endif
