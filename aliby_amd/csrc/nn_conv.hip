@@ -96,6 +96,12 @@ struct ConvArgs {
   const float* shift2;
   const float* bias2;
   int shift2_stride;
+  // first layer as the producer of a pair (k_conv_first_pair): float32 NCHW tiles, <= 2 channels
+  const float* fx;      // [N, fcin, H, W]
+  const float* fw;      // [32][fcin][9] float32 (bf16-representable values)
+  const float* fscale;  // [fcin]
+  const float* fshift;  // [fcin]
+  int fcin;
   unsigned long long* trace;  // diagnostics: per-phase shader-clock stamps of workgroup 0 (NULL in production)
 };
 
@@ -931,6 +937,228 @@ __global__ __launch_bounds__(512, 1) void k_conv_pair32(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The network's first two units in one launch: c0 = conv3x3(act0(tiles)) (the 2-channel first layer, K = 18) feeds
+// x1 = conv3x3(act1(c0)) + proj(tiles) + bias without ever existing in HBM — the separate first-layer launch wrote 0.93 GB of c0
+// and 0.23 GB of raw input per 288-tile forward for the next launch to read back.  Same wave-specialised shape as k_conv_pair32:
+// waves 0-3 (producers) turn the float32 window of tile t + 1 into the activated first-layer input (bf16, zero outside the
+// image), compute the 16 x 32 block of c0 it implies — two MFMA k-steps per 32 pixels, the im2col fragment gathered from LDS as
+// k_first_conv does (k = 12 c + 4 ty + tx) but from a pair-packed window, two ds_read_b32 per four taps — round it to bf16
+// where the two-launch path stores it, run it through unit 1's prologue and write unit 1's channel-octet planes; they also
+// leave the tile's raw pixels (the projection's input) in LDS.  Waves 4-7 (consumers) hold unit 1's weights and the
+// projection's: 9 x 2 + 1 k-steps per output row, in the order of k_conv3x3's fused projection.  Same bits as the two launches.
+struct FirstPairCfg {
+  static constexpr int KC = 2, NPL = 4, R = 2, PASSES = 2;
+  static constexpr int TH = 14, TWO = 30, MH = 16, MW = 32, AH = 18, AW = 36;
+  static constexpr int RAW_MID = MH * MW, PLANE_MID = RAW_MID + (10 - RAW_MID % 8) % 8;
+  static constexpr int MID_SLOTS = NPL * PLANE_MID + 8;     // 16-byte slots
+  static constexpr int P0_WORDS = 2 * AH * AW;              // pair-packed activated window, 32-bit words
+  static constexpr int RAWP_WORDS = MH * MW;                // raw pixels of the tile as (ch0, ch1) bf16 pairs
+  static constexpr int VALS = 2 * AH * AW, ITERS = (VALS + 255) / 256;
+  static constexpr int LDS_BYTES = 2 * MID_SLOTS * 16 + P0_WORDS * 4 + 2 * RAWP_WORDS * 4;
+  static constexpr int DEPTH = 6;
+};
+
+__global__ __launch_bounds__(512, 1) void k_conv_first_pair(ConvArgs a) {
+  using cfg = FirstPairCfg;
+  constexpr int KC = cfg::KC, R = cfg::R, PASSES = cfg::PASSES, TH = cfg::TH, TWO = cfg::TWO, MW = cfg::MW;
+  constexpr int AH = cfg::AH, AW = cfg::AW, PLANE_MID = cfg::PLANE_MID, ITERS = cfg::ITERS;
+  extern __shared__ uint4 lds[];
+  uint4* const ldsMid0 = lds;
+  unsigned* const P0 = reinterpret_cast<unsigned*>(lds + 2 * cfg::MID_SLOTS);
+  unsigned* const rawP0 = P0 + cfg::P0_WORDS;
+  __shared__ __align__(16) float tabB[64];  // unit 1's scale[32], shift[32]
+
+  const int consumer = threadIdx.x >> 8;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 31, hh = lane >> 5;
+  const int c0 = hh * 16;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd + slot, t_end = min(a.ntiles, (xcd + 1) * per_xcd);
+  const int my_tiles = t_begin < t_end ? (t_end - t_begin + nslots - 1) / nslots : 0;
+  const size_t plane = (size_t)a.H * a.W;
+
+  if (!consumer) {
+    // =============================================================== producers: float32 window -> c0 -> unit 1's planes
+    // first-layer weights as MFMA A fragments (row m <-> channel 16*((m>>2)&1) + (m&3) + 4*(m>>3), as k_first_conv)
+    bf16x8_t wF[2];
+    {
+      const int m = lane & 31, co = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        unsigned r4[4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          float v[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int k = 16 * kc + 8 * hh + 2 * j2 + e, c = k / 12, ty = (k % 12) / 4, tx = k % 4;
+            v[e] = (c < a.fcin && tx < 3 && k < 24) ? a.fw[((size_t)co * a.fcin + c) * 9 + ty * 3 + tx] : 0.f;
+          }
+          r4[j2] = cv_pack2(v[0], v[1]);
+        }
+        wF[kc] = __builtin_bit_cast(bf16x8_t, make_uint4(r4[0], r4[1], r4[2], r4[3]));
+      }
+    }
+    // im2col: this lane's two tap groups per k-step as word offsets into P0 (k0 = 16 kc + 8 hh; group g covers k0 + 4g .. + 3,
+    // i.e. (c, ty) = ((k0 + 4g) / 12, ((k0 + 4g) % 12) / 4) and tx = 0..3); groups with k >= 24 meet zero weights and read as zero
+    int goff[2][2];
+    unsigned gmask[2][2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int k = 16 * kc + 8 * hh + 4 * g;
+        const bool live = k < 24 && k / 12 < a.fcin;
+        goff[kc][g] = live ? (k / 12) * AH * AW + ((k % 12) / 4) * AW : 0;
+        gmask[kc][g] = live ? 0xffffffffu : 0u;
+      }
+    if (tid < 32) {
+      tabB[tid] = a.scale2[tid];
+      tabB[32 + tid] = a.shift2[tid];  // (shared by every sample: the first block carries no style shift)
+    }
+    const float fs0 = a.fscale[0], fh0 = a.fshift[0];
+    const float fs1 = a.fcin > 1 ? a.fscale[1] : 0.f, fh1 = a.fcin > 1 ? a.fshift[1] : 0.f;
+    // the float32 window of tile t + 1 is requested while tile t's c0 is on the matrix cores
+    float v[ITERS];
+    unsigned inside = 0;
+    auto request = [&](int tile) {
+      const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+      const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TWO;
+      inside = 0;
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) {
+        const int i = tid + 256 * u;
+        const int c = i / (AH * AW), rem = i - c * (AH * AW), r = rem / AW, q = rem - r * AW;
+        const int gy = y0 - 2 + r, gx = x0 - 2 + q;
+        const bool ok = i < cfg::VALS && c < a.fcin && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        inside |= (unsigned)ok << u;
+        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1), cc = min(c, a.fcin - 1);
+        v[u] = a.fx[((size_t)n * a.fcin + cc) * plane + (size_t)cy * a.W + cx];
+      }
+    };
+    if (my_tiles > 0) request(t_begin);
+    unsigned short* const P0h = reinterpret_cast<unsigned short*>(P0);
+    for (int it = 0; it < my_tiles; ++it) {
+      const int tile = t_begin + it * nslots;
+      const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+      const int ty = tyn % a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TWO;
+      uint4* const ldsMid = ldsMid0 + (it & 1) * cfg::MID_SLOTS;
+      unsigned short* const rawPh = reinterpret_cast<unsigned short*>(rawP0 + (it & 1) * cfg::RAWP_WORDS);
+      // ---- activated window, pair-packed: word (c, r, q) = act(q) | act(q + 1) << 16 (k_first_conv's arithmetic: separate multiply
+      // and add, ReLU in float, then round to bf16; zero outside the image), and the tile's raw pixels for the projection
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) {
+        const int i = tid + 256 * u;
+        if (i >= cfg::VALS) break;
+        const int c = i / (AH * AW), rem = i - c * (AH * AW), r = rem / AW, q = rem - r * AW;
+        const bool ok = (inside >> u) & 1u;
+        const float t = ok ? fmaxf(v[u] * (c ? fs1 : fs0) + (c ? fh1 : fh0), 0.f) : 0.f;
+        const unsigned short b = (unsigned short)(cv_pack2(t, 0.f) & 0xffffu);
+        P0h[2 * i] = b;                       // low half of word (c, r, q)
+        if (q > 0) P0h[2 * (i - 1) + 1] = b;  // high half of word (c, r, q - 1)
+        if (q == AW - 1) P0h[2 * i + 1] = 0;
+        // raw pixel (image row y0 + r - 2, column x0 + q - 2) of the output tile: rows 2..17 of the window, columns 2..33
+        if (r >= 2 && q >= 2 && q < 2 + MW)
+          rawPh[2 * ((r - 2) * MW + (q - 2)) + c] = (unsigned short)(cv_pack2(ok ? v[u] : 0.f, 0.f) & 0xffffu);
+      }
+      if (a.fcin < 2) {  // the second channel of the raw pairs is zero
+        for (int i = tid; i < cfg::RAWP_WORDS; i += 256) rawPh[2 * i + 1] = 0;
+      }
+      __syncthreads();  // S1: the window is complete
+      if (it + 1 < my_tiles) request(tile + nslots);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int mbase = (wave * PASSES + pass) * R;  // first c0 row of this wave and pass (image row y0 - 1 + mbase)
+        const int mgx = x0 - 1 + px;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int m = mbase + r;
+          f32x16_t acc;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) {
+            const unsigned* w0 = P0 + goff[kc][0] + m * AW + px;
+            const unsigned* w1 = P0 + goff[kc][1] + m * AW + px;
+            const uint4 bfrag = make_uint4(w0[0] & gmask[kc][0], w0[2] & gmask[kc][0], w1[0] & gmask[kc][1], w1[2] & gmask[kc][1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wF[kc], __builtin_bit_cast(bf16x8_t, bfrag), acc, 0, 0, 0);
+          }
+          // bf16 as the first-layer launch stores c0, then unit 1's prologue; zero where the c0 pixel lies outside the image
+          const int mgy = y0 - 1 + m;
+          const unsigned keep = 0u - (unsigned)((unsigned)mgy < (unsigned)a.H && (unsigned)mgx < (unsigned)a.W);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            f32x2_t s2[4], h2[4];
+            const float4* tp = reinterpret_cast<const float4*>(tabB + c0 + 8 * half);
+            const float4 sa = tp[0], sb = tp[1], ha = tp[8], hb = tp[9];
+            s2[0] = f32x2_t{sa.x, sa.y}; s2[1] = f32x2_t{sa.z, sa.w}; s2[2] = f32x2_t{sb.x, sb.y}; s2[3] = f32x2_t{sb.z, sb.w};
+            h2[0] = f32x2_t{ha.x, ha.y}; h2[1] = f32x2_t{ha.z, ha.w}; h2[2] = f32x2_t{hb.x, hb.y}; h2[3] = f32x2_t{hb.z, hb.w};
+            const uint4 raw = make_uint4(cv_pack2(acc[8 * half + 0], acc[8 * half + 1]), cv_pack2(acc[8 * half + 2], acc[8 * half + 3]),
+                                         cv_pack2(acc[8 * half + 4], acc[8 * half + 5]), cv_pack2(acc[8 * half + 6], acc[8 * half + 7]));
+            ldsMid[(2 * hh + half) * PLANE_MID + m * MW + px] = conv_act8(raw, s2, h2, keep);
+          }
+        }
+      }
+      __syncthreads();  // S2: planes[it & 1] and rawP[it & 1] are complete; the window may be overwritten
+    }
+    __syncthreads();  // the consumers' last tile: its S1 ...
+    __syncthreads();  // ... and S2
+  } else {
+    // =============================================================== consumers: unit 1's planes (+ raw pixels) -> OUT
+    bf16x8_t wB[9 * KC];
+    {
+      const bf16x8_t* pb = reinterpret_cast<const bf16x8_t*>(a.wpk2) + lane;
+#pragma unroll
+      for (int i = 0; i < 9 * KC; ++i) wB[i] = pb[i * 64];
+    }
+    const bf16x8_t pfrag = (reinterpret_cast<const bf16x8_t*>(a.pwpk) + lane)[0];
+    float4 b4[4] = {};
+    if (a.bias2) {
+      const float4* bp = reinterpret_cast<const float4*>(a.bias2 + c0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+    }
+    __syncthreads();  // the producers' first tile: its S1 ...
+    __syncthreads();  // ... and S2
+    for (int it = 0; it < my_tiles; ++it) {
+      const int tile = t_begin + it * nslots;
+      const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
+      const int ty = tyn % a.tiles_y, n = tyn / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TWO;
+      const uint4* const ldsMid = ldsMid0 + (it & 1) * cfg::MID_SLOTS;
+      const unsigned* const rawP = rawP0 + (it & 1) * cfg::RAWP_WORDS;
+      const int gx = (px < TWO && x0 + px < a.W) ? x0 + px : a.W;  // a.W: this lane stores nothing
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        const int rbase = (wave * PASSES + pass) * R;
+        if (rbase < TH) {  // (the last wave's second pass has no rows)
+          f32x16_t acc[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[r][4 * q] = b4[q].x; acc[r][4 * q + 1] = b4[q].y; acc[r][4 * q + 2] = b4[q].z; acc[r][4 * q + 3] = b4[q].w; }
+          __builtin_amdgcn_sched_barrier(0);
+          conv_mfma<R, KC, cfg::DEPTH, PLANE_MID, MW>(reinterpret_cast<const bf16x8_t*>(ldsMid) + hh * PLANE_MID + rbase * MW + px, wB, acc);
+          // the projection of the raw pixels: one more k-step (channels 0-1 real, the rest of the 16 zero)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const unsigned w = hh ? 0u : rawP[(rbase + r) * MW + px];
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pfrag, __builtin_bit_cast(bf16x8_t, make_uint4(w, 0u, 0u, 0u)), acc[r], 0, 0, 0);
+          }
+          conv_store<R>(a, n, 0, y0 + rbase, gx, c0, acc);
+        }
+        __syncthreads();  // pass 0: the producers' S1 of tile it + 1 (or their drain); pass 1: S2
+      }
+    }
+  }
+}
+
 // Packed layout: [cout block cb][tap][k-step kc][lane][8 bf16]; lane l holds the MFMA A fragment
 // A[row m = l&31][k = 8*(l>>5) + j] = W[cb*32 + chan(m)][cin = 16*kc + 8*(l>>5) + j][tap], with
 // chan(m) = 16*((m>>2)&1) + (m&3) + 4*(m>>3) (see the header comment).
@@ -1193,6 +1421,37 @@ extern "C" int aliby_nn_conv3x3_pair_bf16(aliby_ctx* ctx, const void* in, const 
   if (head_out) hipLaunchKernelGGL((k_conv_pair32<false, true>), grid, block, PairCfg::LDS_BYTES, stream, a);
   else if (pool_out) hipLaunchKernelGGL((k_conv_pair32<true, false>), grid, block, PairCfg::LDS_BYTES, stream, a);
   else hipLaunchKernelGGL((k_conv_pair32<false, false>), grid, block, PairCfg::LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+extern "C" int aliby_nn_first_pair_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W, const float* scale0,
+                                        const float* shift0, const float* w_oihw, const void* wpk1, const float* scale1,
+                                        const float* shift1, const float* bias1, const void* proj_wpk, void* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  ARG_CHECK(ctx && tiles && scale0 && shift0 && w_oihw && wpk1 && scale1 && shift1 && bias1 && proj_wpk && out, "first_pair: null argument");
+  ARG_CHECK(N > 0 && H > 0 && W > 0 && Cin >= 1 && Cin <= 2, "first_pair: Cin must be 1 or 2");
+  ConvArgs a = {};
+  a.fx = tiles; a.fw = w_oihw; a.fscale = scale0; a.fshift = shift0; a.fcin = Cin;
+  a.wpk2 = static_cast<const uint4*>(wpk1);
+  a.scale2 = scale1; a.shift2 = shift1; a.bias2 = bias1; a.shift2_stride = 0;
+  a.pwpk = static_cast<const uint4*>(proj_wpk);
+  a.out = static_cast<uint4*>(out);
+  a.cs = 4; a.coff = 0; a.ocs = 4; a.ocoff = 0;
+  a.N = N; a.H = H; a.W = W; a.G = 1;
+  a.tiles_x = (W + FirstPairCfg::TWO - 1) / FirstPairCfg::TWO;
+  a.tiles_y = (H + FirstPairCfg::TH - 1) / FirstPairCfg::TH;
+  const long long nt = (long long)N * a.tiles_x * a.tiles_y;
+  ARG_CHECK(nt < INT_MAX, "first_pair: too many tiles");
+  a.ntiles = (int)nt;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_first_pair), hipFuncAttributeMaxDynamicSharedMemorySize, FirstPairCfg::LDS_BYTES));
+    attr_done = true;
+  }
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int nslots = per_xcd < 32 ? per_xcd : 32;  // one 8-wave workgroup per CU, 32 CUs per XCD
+  hipLaunchKernelGGL(k_conv_first_pair, dim3(8 * nslots), dim3(512), FirstPairCfg::LDS_BYTES, stream, a);
   KERNEL_CHECK();
   return ALIBY_OK;
 }

@@ -83,6 +83,7 @@ class FusedUNet:
         self.mfma_levels = tuple(mfma_levels)
         self.fused_head = os.environ.get("ALIBY_NET_FUSED_HEAD", "1") != "0"
         self.fused_pair = os.environ.get("ALIBY_NET_FUSED_PAIR", "1") != "0"  # level 0: conv2 + conv3 of a block in one launch
+        self.fused_first = os.environ.get("ALIBY_NET_FUSED_FIRST", "1") != "0"  # the first layer + conv1 + projection in one launch
         # deep levels (128 / 256 channels): one K-loop launch per convolution (csrc/nn_conv_deep.hip); 0 = the K/N-slice launches
         self.deep_kernel = os.environ.get("ALIBY_CONV_DEEP", "1") != "0"
         self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
@@ -236,6 +237,28 @@ class FusedUNet:
                 self.out_w.shape[0] if head_out is not None else 0, _ptr(head_out) if head_out is not None else 0, _stream_ptr()))
         return (out, pooled) if pool else out
 
+    def _first_pair(self, tiles, d):
+        """The first layer, the block's second unit and its 1x1 projection in one launch (aliby_nn_first_pair_bf16): neither c0 nor
+        the raw bf16 copy of the tiles is written to HBM.  Same bits as first_conv -> _unit_proj."""
+        n, cin, H, W = tiles.shape
+        u, proj = d["u"], d["proj"]
+        wpk1 = self._pack(u[1])
+        if proj.wpk is None:
+            proj.wpk = torch.empty(32 * 16, dtype=torch.bfloat16, device="cuda")
+            _lib.check(self.lib.aliby_nn_pack_conv1x1_bf16(self.h, _ptr(proj.w32), 32, proj.w32.shape[1], 16, _ptr(proj.wpk), _stream_ptr()))
+        out = self._new(n, 32, H, W)
+        group = "conv3x3_mfma_first_pair"
+        timer = self.eng.timed(group)
+        if timer.active:
+            st = self.conv_stats.setdefault(group, [0, 0])
+            st[0] += 4 * tiles.numel() + 2 * out.numel()
+            st[1] += 2 * (9 * cin + 9 * 32 + cin) * 32 * n * H * W
+        with timer:
+            _lib.check(self.lib.aliby_nn_first_pair_bf16(
+                self.h, _ptr(tiles), n, cin, H, W, _ptr(u[0].scale), _ptr(u[0].shift), _ptr(self.first_w), _ptr(wpk1), _ptr(u[1].scale),
+                _ptr(d["shift1_b0"]), _ptr(d["pb1"]), _ptr(proj.wpk), _ptr(out), _stream_ptr()))
+        return out
+
     def _unit_head(self, x, unit, shift, bias, res, y):
         """The network's last unit with the output head in its epilogue (aliby_nn_conv3x3_head_bf16): y float32 [N,O,H,W]
         is written from the accumulators and the unit's own bf16 output — which nothing else reads — is not written."""
@@ -350,9 +373,15 @@ class FusedUNet:
         """shift_per_sample argument of the kernels: 0 shared, else the row stride in floats."""
         return 0 if sh.ndim == 1 else sh.stride(0)
 
-    def _down_mfma(self, i, d, x_raw, x_act):
-        """Residual down block on the MFMA unit: 4 launches, no pointwise passes."""
+    def _down_mfma(self, i, d, x_raw, x_act, x1=None):
+        """Residual down block on the MFMA unit: 4 launches, no pointwise passes (x1 given: the first two units already ran)."""
         u = d["u"]
+        if x1 is not None:
+            pool = i + 1 < len(self.down) and u[3].w32.shape[0] <= 128
+            if self.fused_pair and tuple(u[2].w32.shape[:2]) == (32, 32) and tuple(u[3].w32.shape[:2]) == (32, 32):
+                return self._pair(x1, u[2], u[3], None, None, u[2].bias, u[3].bias, x1, pool=pool)
+            c2 = self._unit(x1, u[2], bias=u[2].bias)
+            return self._unit(c2, u[3], bias=u[3].bias, res=x1, pool=pool)
         fuse_proj = (u[1].w32.shape[1], u[1].w32.shape[0]) in ((32, 32), (64, 64))  # projection rides in conv1's launch
         p = None if fuse_proj else self._proj(x_raw, d["proj"])
         if i == 0:  # 2 -> 32 channels: K = 18 is too thin for the matrix cores; c0 comes from the first-layer kernel (or
@@ -394,9 +423,16 @@ class FusedUNet:
         `out`, when given, is the contiguous float32 [N,3,H,W] buffer y is written into (no copy afterwards)."""
         n, cin, H, W = tiles.shape
         d0 = self.down[0]
-        raw = self._new(n, 8, H, W)
         self._first_c0 = 0 in self.mfma_levels and cin <= 2
-        if self._first_c0:  # first-layer kernel: `act` IS c0 = conv3x3(relu(bn(x))) (32 channels), no MIOpen call
+        u0 = d0["u"]
+        x1_first = None
+        if (self._first_c0 and self.fused_first and tuple(u0[1].w32.shape[:2]) == (32, 32) and u0[0].w32.shape[0] == 32
+                and d0["proj"].w32.shape[0] == 32):
+            x1_first = self._first_pair(tiles.contiguous(), d0)
+        raw = self._new(n, 8, H, W) if x1_first is None else None
+        if x1_first is not None:
+            act = None
+        elif self._first_c0:  # first-layer kernel: `act` IS c0 = conv3x3(relu(bn(x))) (32 channels), no MIOpen call
             act = self._new(n, 32, H, W)
             with self.eng.timed("first_conv"):
                 _lib.check(self.lib.aliby_nn_first_conv_bf16(self.h, _ptr(tiles), n, cin, H, W, _ptr(d0["u"][0].scale), _ptr(d0["u"][0].shift),
@@ -413,7 +449,7 @@ class FusedUNet:
                 x_raw = pooled if pooled is not None else F.max_pool2d(feats[-1], 2, 2)
                 pooled = None
             if i in self.mfma_levels:
-                x2 = self._down_mfma(i, d, x_raw, x_act)
+                x2 = self._down_mfma(i, d, x_raw, x_act, x1=x1_first if i == 0 else None)
                 if isinstance(x2, tuple):
                     x2, pooled = x2  # the block's last convolution also wrote the next level's input
                 feats.append(x2)

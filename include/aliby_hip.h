@@ -228,6 +228,15 @@ int aliby_nn_conv3x3_head_bf16(aliby_ctx* ctx, const void* in, const void* wpk, 
                                int N, int H, int W, int CIN, int COUT, const float* head_scale,
                                const float* head_shift, const float* head_w, const float* head_bias, int head_channels,
                                float* head_out, void* stream);
+/* The network's first two units in ONE launch (round 3): x1 = conv3x3(act1(conv3x3(act0(tiles)))) + proj(tiles) + bias1 — what
+ * aliby_nn_first_conv_bf16 followed by aliby_nn_conv3x3_proj_bf16 compute, without the first layer's output (c0, 32 channels)
+ * and the raw bf16 copy of the tiles ever reaching HBM: same bits as the two launches.  tiles float32 [N, Cin <= 2, H, W];
+ * scale0 / shift0 [Cin] and w_oihw [32][Cin][9] as in aliby_nn_first_conv_bf16; wpk1 the second unit's packed weights
+ * (32 -> 32), scale1 / shift1 [32] its prologue (shift1 already carries the first layer's bias), bias1 [32] its bias plus the
+ * projection's; proj_wpk the projection packed with aliby_nn_pack_conv1x1_bf16(..., CIN = 16).  out [N, H, W, 32] bf16. */
+int aliby_nn_first_pair_bf16(aliby_ctx* ctx, const float* tiles, int N, int Cin, int H, int W, const float* scale0,
+                             const float* shift0, const float* w_oihw, const void* wpk1, const float* scale1,
+                             const float* shift1, const float* bias1, const void* proj_wpk, void* out, void* stream);
 /* Two consecutive 32 -> 32 units of a residual block in ONE launch (cellpose resdown / resup: x + conv3(conv2(x)),
  * segment/unet.py): out = conv_b(act_b(conv_a(act_a(in)) + bias_a)) + bias_b + res, the tensor in between kept in LDS
  * (rounded to bf16 where the two-launch path stores it: same bits as two aliby_nn_conv3x3_bf16 launches).  An 8-wave

@@ -506,3 +506,48 @@ def test_maxpool2_bf16(engine):
     torch.cuda.synchronize()
     ref = torch.nn.functional.max_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
     assert torch.equal(out.float(), ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 44, 70), (1, 10, 6), (5, 14, 30), (2, 16, 62), (1, 2, 2), (2, 31, 33)])
+@pytest.mark.parametrize("cin", [2, 1])
+def test_first_pair_equals_first_conv_then_projected_unit(engine, shape, cin):
+    """aliby_nn_first_pair_bf16 (round 3: the first layer as the producer of the second unit, neither c0 nor the raw bf16 copy
+    in HBM) against the two launches it replaces — aliby_nn_first_conv_bf16 then aliby_nn_conv3x3_proj_bf16 — bit for bit, on
+    tiles that do and do not divide by 14 x 30, one and two input channels."""
+    import torch
+    from aliby_amd import _lib
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+
+    n, H, W = shape
+    g = torch.Generator().manual_seed(n * 17 + H + cin)
+    tiles = (torch.randn(n, cin, H, W, generator=g) * 2.0).float().cuda().contiguous()
+    s0 = torch.zeros(8).float()
+    h0 = torch.zeros(8).float()
+    s0[:cin] = torch.rand(cin, generator=g) + 0.5
+    h0[:cin] = torch.randn(cin, generator=g) * 0.3
+    s0, h0 = s0.cuda(), h0.cuda()
+    w0 = (torch.randn(32, cin, 3, 3, generator=g) * 0.3).to(torch.bfloat16).float().cuda().contiguous()  # bf16-representable
+    w1 = (torch.randn(32, 32, 3, 3, generator=g) * 0.06).float().cuda()
+    wpk1 = torch.empty(32 * 32 * 9, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w1), 32, 32, 32, _ptr(wpk1), _stream_ptr()))
+    s1 = (torch.rand(32, generator=g) + 0.5).float().cuda()
+    h1 = (torch.randn(32, generator=g) * 0.2).float().cuda()
+    b1 = (torch.randn(32, generator=g) * 0.1).float().cuda()
+    wp = torch.zeros(32, 8)
+    wp[:, :cin] = torch.randn(32, cin, generator=g) * 0.4
+    wp = wp.float().cuda().contiguous()
+    ppk = torch.empty(32 * 16, dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_pack_conv1x1_bf16(engine.ctx.handle, _ptr(wp), 32, 8, 16, _ptr(ppk), _stream_ptr()))
+    raw = torch.full((n, H, W, 8), float("nan"), dtype=torch.bfloat16, device="cuda")
+    c0 = torch.full((n, H, W, 32), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_first_conv_bf16(engine.ctx.handle, _ptr(tiles), n, cin, H, W, _ptr(s0), _ptr(h0), _ptr(w0), _ptr(raw), _ptr(c0),
+                                                   _stream_ptr()))
+    want = torch.full((n, H, W, 32), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(engine.lib.aliby_nn_conv3x3_proj_bf16(engine.ctx.handle, _ptr(c0), _ptr(wpk1), _ptr(want), _ptr(s1), _ptr(h1), 0, _ptr(b1), n, H, W,
+                                                     32, 32, _ptr(raw), _ptr(ppk), 8, _stream_ptr()))
+    got = torch.full_like(want, float("nan"))
+    _lib.check(engine.lib.aliby_nn_first_pair_bf16(engine.ctx.handle, _ptr(tiles), n, cin, H, W, _ptr(s0), _ptr(h0), _ptr(w0), _ptr(wpk1), _ptr(s1),
+                                                   _ptr(h1), _ptr(b1), _ptr(ppk), _ptr(got), _stream_ptr()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(want.float()).any()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))

@@ -341,3 +341,23 @@ def test_masks_are_stable_under_the_networks_numeric_error(engine):
         pathlib.Path("gpurun_out/mask_stability.json").write_text(json.dumps(report, indent=1))
     except OSError:
         pass
+
+
+def test_network_with_fused_first_pair_matches_the_separate_launches(engine):
+    """Round 3: the first layer + second unit + projection of the network run as one launch (FusedUNet.fused_first); the whole
+    forward gives exactly the bits of the path with the separate first-layer launch."""
+    import warnings
+
+    import torch
+    from aliby_amd.segment.cellpose_hip import CellposeModel
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = CellposeModel(net_dtype="bfloat16", seed=5, batch_size=4)
+    f = synth.make_fov(1, 9, shape=(300, 420), n_target=12)
+    img = torch.from_numpy(f["pixels"][0, 0][None]).cuda()
+    assert model.fused is not None and model.fused.fused_first
+    got = model.run_network(img)
+    model.fused.fused_first = False
+    want = model.run_network(img)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
