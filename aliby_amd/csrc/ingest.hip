@@ -291,6 +291,171 @@ bool inflate_any(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t& out
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------ Blosc (version 1 frames)
+// zarr v2's default compressor is Blosc(cname="lz4", clevel=5, shuffle=SHUFFLE) (numcodecs), so a "Zarr-backed" store
+// (reference: ImageZarr, src/aliby/io/image.py:236-264) is normally a directory of Blosc frames.  c-blosc is not in the image;
+// the frame format is small (c-blosc README_HEADER.rst, blosc.c blosc_d):
+//   header, 16 bytes: version, versionlz, flags, typesize, nbytes u32, blocksize u32, cbytes u32 (little endian)
+//     flags: 0x1 byte shuffle, 0x2 memcpyed (raw bytes follow the header), 0x4 bit shuffle, 0x10 blocks are not split,
+//            bits 5-7 the codec: 0 blosclz, 1 lz4 / lz4hc, 2 snappy, 3 zlib, 4 zstd
+//   then one int32 offset per block (from the frame start); a block is `nsplits` streams, each int32 length + data, a stream
+//   whose length equals its uncompressed size is stored raw; nsplits = typesize for full blocks of >= 128 elements of <= 16
+//   bytes unless 0x10 is set, else 1; the decoded block is un-shuffled per block (byte planes; or bit planes when the block holds a
+//   multiple of 8 elements, else it was stored unshuffled; bytes past the last whole element are copied as they are).
+// LZ4 blocks and blosclz are decoded here by hand; zlib and zstd streams go through the decoders above.
+bool unlz4_block(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t& out) {
+  size_t ip = 0, op = 0;
+  while (ip < n) {
+    const unsigned token = s[ip++];
+    size_t lit = token >> 4;
+    if (lit == 15) {
+      unsigned b;
+      do { if (ip >= n) return false; b = s[ip++]; lit += b; } while (b == 255);
+    }
+    if (lit > n - ip || lit > cap - op) return false;
+    memcpy(d + op, s + ip, lit);
+    ip += lit;
+    op += lit;
+    if (ip >= n) break;  // the last sequence is literals only
+    if (n - ip < 2) return false;
+    const size_t off = (size_t)s[ip] | ((size_t)s[ip + 1] << 8);
+    ip += 2;
+    if (off == 0 || off > op) return false;
+    size_t len = (token & 15u);
+    if (len == 15) {
+      unsigned b;
+      do { if (ip >= n) return false; b = s[ip++]; len += b; } while (b == 255);
+    }
+    len += 4;
+    if (len > cap - op) return false;
+    for (size_t k = 0; k < len; ++k) d[op + k] = d[op + k - off];  // (overlapping copies repeat the pattern)
+    op += len;
+  }
+  out = op;
+  return true;
+}
+
+bool unblosclz(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t& out) {
+  if (n == 0) return false;
+  size_t ip = 0, op = 0;
+  unsigned ctrl = s[ip++] & 31u;
+  for (;;) {
+    if (ctrl >= 32) {
+      size_t len = (ctrl >> 5) - 1, ofs = (size_t)(ctrl & 31u) << 8;
+      if (len == 7 - 1) {
+        unsigned code;
+        do { if (ip >= n) return false; code = s[ip++]; len += code; } while (code == 255);
+      }
+      if (ip >= n) return false;
+      const unsigned code = s[ip++];
+      size_t dist = ofs + code + 1;  // ref = op - ofs - code, the copy starts at ref - 1
+      if (code == 255 && ofs == (31u << 8)) {  // far match: 16-bit distance beyond the 13-bit window
+        if (n - ip < 2) return false;
+        const size_t far = ((size_t)s[ip] << 8) | s[ip + 1];
+        ip += 2;
+        dist = far + 8191 + 1;
+      }
+      len += 3;
+      if (dist > op || len > cap - op) return false;
+      for (size_t k = 0; k < len; ++k) d[op + k] = d[op + k - dist];
+      op += len;
+    } else {
+      const size_t run = ctrl + 1;
+      if (run > n - ip || run > cap - op) return false;
+      memcpy(d + op, s + ip, run);
+      ip += run;
+      op += run;
+    }
+    if (ip >= n) break;
+    ctrl = s[ip++];
+  }
+  out = op;
+  return true;
+}
+
+void blosc_unshuffle(const uint8_t* src, uint8_t* dst, size_t n, size_t ts) {  // byte planes -> elements
+  const size_t ne = n / ts;
+  for (size_t j = 0; j < ts; ++j) {
+    const uint8_t* plane = src + j * ne;
+    for (size_t i = 0; i < ne; ++i) dst[i * ts + j] = plane[i];
+  }
+  memcpy(dst + ne * ts, src + ne * ts, n - ne * ts);
+}
+
+void blosc_bitunshuffle(const uint8_t* src, uint8_t* dst, size_t n, size_t ts) {  // bit planes -> elements
+  // (c-blosc shuffle.c, bitshuffle(): a block whose element count is not a multiple of 8 is stored as it is)
+  if ((n / ts) % 8 != 0) { memcpy(dst, src, n); return; }
+  const size_t ne = n / ts, rows = ne / 8;  // bit plane (byte j, bit b) is `rows` bytes: bit k of byte r = element 8 r + k
+  memset(dst, 0, ne * ts);
+  for (size_t j = 0; j < ts; ++j)
+    for (unsigned b = 0; b < 8; ++b) {
+      const uint8_t* plane = src + (j * 8 + b) * rows;
+      for (size_t r = 0; r < rows; ++r) {
+        const unsigned byte = plane[r];
+        for (unsigned k = 0; k < 8; ++k) dst[(8 * r + k) * ts + j] |= (uint8_t)(((byte >> k) & 1u) << b);
+      }
+    }
+  memcpy(dst + ne * ts, src + ne * ts, n - ne * ts);
+}
+
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+bool unblosc(const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t& out, std::string& err) {
+  if (n < 16) { err = "Blosc frame shorter than its header"; return false; }
+  const unsigned version = s[0], flags = s[2], ts = s[3] ? s[3] : 1;
+  const size_t nbytes = rd32(s + 4), blocksize = rd32(s + 8), cbytes = rd32(s + 12);
+  if (version != 2) { err = "Blosc frame version " + std::to_string(version) + " is not supported (2 is)"; return false; }
+  if (cbytes > n || cbytes < 16) { err = "Blosc frame is truncated"; return false; }
+  if (nbytes > cap) { err = "Blosc frame holds " + std::to_string(nbytes) + " bytes, the chunk has room for " + std::to_string(cap); return false; }
+  out = nbytes;
+  if (nbytes == 0) return true;
+  if (flags & 0x2) {  // memcpyed
+    if (cbytes < 16 + nbytes) { err = "Blosc frame is truncated"; return false; }
+    memcpy(d, s + 16, nbytes);
+    return true;
+  }
+  if (blocksize == 0 || blocksize > (1u << 31)) { err = "Blosc frame has an invalid block size"; return false; }
+  const unsigned codec = flags >> 5;
+  const bool shuffle = flags & 0x1, bitshuffle = flags & 0x4, dont_split = flags & 0x10;
+  const size_t nblocks = (nbytes + blocksize - 1) / blocksize;
+  if (nblocks > (cbytes - 16) / 4) { err = "Blosc frame is truncated (block offsets)"; return false; }
+  std::vector<uint8_t> tmp((shuffle || bitshuffle) ? (blocksize < nbytes ? blocksize : nbytes) : 0);
+  for (size_t b = 0; b < nblocks; ++b) {
+    const size_t start = rd32(s + 16 + 4 * b);
+    const size_t bsize = b + 1 < nblocks ? blocksize : nbytes - b * blocksize;
+    const bool leftover = bsize != blocksize;
+    const size_t nsplits = (!dont_split && !leftover && ts <= 16 && blocksize / ts >= 128) ? ts : 1;
+    const size_t neblock = bsize / nsplits;
+    uint8_t* target = (shuffle || bitshuffle) ? tmp.data() : d + b * blocksize;
+    size_t ip = start;
+    for (size_t k = 0; k < nsplits; ++k) {
+      if (ip > cbytes || cbytes - ip < 4) { err = "Blosc block runs past the frame"; return false; }
+      const size_t clen = rd32(s + ip);
+      ip += 4;
+      if (clen > cbytes - ip) { err = "Blosc stream runs past the frame"; return false; }
+      uint8_t* dst = target + k * neblock;
+      if (clen == neblock) {
+        memcpy(dst, s + ip, neblock);
+      } else {
+        size_t got = 0;
+        bool ok;
+        switch (codec) {
+          case 0: ok = unblosclz(s + ip, clen, dst, neblock, got); break;
+          case 1: ok = unlz4_block(s + ip, clen, dst, neblock, got); break;
+          case 3: ok = inflate_any(s + ip, clen, dst, neblock, got, err); break;
+          case 4: ok = unzstd(s + ip, clen, dst, neblock, got, err); break;
+          default: err = "Blosc codec " + std::to_string(codec) + " is not supported (blosclz, lz4, zlib, zstd are)"; return false;
+        }
+        if (!ok || got != neblock) { if (err.empty()) err = "Blosc stream is corrupt"; return false; }
+      }
+      ip += clen;
+    }
+    if (bitshuffle) blosc_bitunshuffle(tmp.data(), d + b * blocksize, bsize, ts);
+    else if (shuffle) blosc_unshuffle(tmp.data(), d + b * blocksize, bsize, ts);
+  }
+  return true;
+}
+
 bool decompress(int scheme, const uint8_t* s, size_t n, uint8_t* d, size_t cap, size_t& out, std::string& err) {
   switch (scheme) {
     case 1:
@@ -577,7 +742,7 @@ int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int
   }
 }
 
-// Chunk decompression for zarr stores: codec 0 = zlib / gzip, 1 = Zstandard.  *out_bytes = bytes produced.
+// Chunk decompression for zarr stores: codec 0 = zlib / gzip, 1 = Zstandard, 2 = a Blosc-1 frame.  *out_bytes = bytes produced.
 int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst, size_t dst_bytes, size_t* out_bytes) {
   ARG_CHECK(src && dst && out_bytes, "buffers must be given");
   try {
@@ -586,6 +751,7 @@ int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst
   bool ok;
   if (codec == 0) ok = inflate_any((const uint8_t*)src, src_bytes, (uint8_t*)dst, dst_bytes, got, err);
   else if (codec == 1) ok = unzstd((const uint8_t*)src, src_bytes, (uint8_t*)dst, dst_bytes, got, err);
+  else if (codec == 2) ok = unblosc((const uint8_t*)src, src_bytes, (uint8_t*)dst, dst_bytes, got, err);
   else { aliby_set_error("unknown codec %d", codec); return ALIBY_ERR_UNSUPPORTED; }
   if (!ok) { aliby_set_error("%s", err.c_str()); return ALIBY_ERR_INVALID; }
   *out_bytes = got;

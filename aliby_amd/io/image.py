@@ -11,8 +11,9 @@ Mirrors src/aliby/io/image.py — `dispatch_image` (53-74), `instantiate_image` 
   `read_device(tp)`: the planes of one time point are decoded by `aliby_ingest_tiff_planes` (csrc/ingest.hip) into
   pinned staging memory by a pool of host threads and uploaded plane by plane while the rest still decode.
 * TIFF and zarr are read by this package (no tifffile / imageio / zarr / numcodecs in the image): baseline TIFF + BigTIFF
-  with the compressions listed in include/aliby_hip.h; zarr v2 and v3 directory stores with no / zlib / gzip / zstd
-  compression (Blosc and sharding raise NotImplementedError with the codec's name).
+  with the compressions listed in include/aliby_hip.h; zarr v2 and v3 directory stores with no / zlib / gzip / zstd / Blosc
+  compression (Blosc-1 frames — zarr v2's default compressor — are decoded by csrc/ingest.hip: blosclz, lz4, zlib, zstd streams,
+  byte and bit shuffle; sharding raises NotImplementedError with the codec's name).
 """
 
 from __future__ import annotations
@@ -145,14 +146,14 @@ class ZarrSource:
                 name = codec["name"]
                 if name == "bytes":
                     endian = "<" if (codec.get("configuration") or {}).get("endian", "little") == "little" else ">"
-                elif name in ("gzip", "zlib", "zstd"):
+                elif name in ("gzip", "zlib", "zstd", "blosc"):
                     self.codec = name
                 elif name == "transpose":
                     order = tuple((codec.get("configuration") or {}).get("order", ()))
                     if order != tuple(range(len(self.shape))):
                         raise NotImplementedError("zarr v3 transpose codec is not supported")
                 else:
-                    raise NotImplementedError(f"zarr codec '{name}' is not supported (bytes, gzip, zlib, zstd are)")
+                    raise NotImplementedError(f"zarr codec '{name}' is not supported (bytes, gzip, zlib, zstd, blosc are)")
             self.dtype = np.dtype(meta["data_type"]).newbyteorder(endian)
             enc = meta.get("chunk_key_encoding", {"name": "default"})
             sep = (enc.get("configuration") or {}).get("separator", "/" if enc.get("name", "default") == "default" else ".")
@@ -160,8 +161,8 @@ class ZarrSource:
             self._key = lambda idx: (prefix + sep.join(map(str, idx))) if idx else "c"
         else:
             raise FileNotFoundError(f"no zarr array at {self.root}")
-        if self.codec not in (None, "zlib", "gzip", "zstd"):
-            raise NotImplementedError(f"zarr compressor '{self.codec}' is not supported (none, zlib, gzip, zstd are)")
+        if self.codec not in (None, "zlib", "gzip", "zstd", "blosc"):
+            raise NotImplementedError(f"zarr compressor '{self.codec}' is not supported (none, zlib, gzip, zstd, blosc are)")
 
     def _chunk(self, idx):
         path = self.root / self._key(idx)
@@ -175,7 +176,7 @@ class ZarrSource:
             src = np.frombuffer(raw, np.uint8)
             _lib.check(
                 _lib.load().aliby_ingest_inflate(
-                    1 if self.codec == "zstd" else 0, src.ctypes.data, src.size, out.ctypes.data, out.size, C.byref(got)
+                    {"zstd": 1, "blosc": 2}.get(self.codec, 0), src.ctypes.data, src.size, out.ctypes.data, out.size, C.byref(got)
                 )
             )
             if got.value != out.size:

@@ -455,7 +455,8 @@ int aliby_tiff_probe(const char* path, int64_t* info, char* description, int des
 int aliby_ingest_tiff_planes(aliby_ctx* ctx, const char* const* paths, const int32_t* pages, int n, int width,
                              int height, int bytes_per_sample, void* dst, size_t plane_stride, int dst_is_device,
                              int n_threads, void* stream);
-/* One compressed zarr chunk -> dst; codec 0 = zlib / gzip, 1 = Zstandard (libzstd.so.1 loaded on first use). */
+/* One compressed zarr chunk -> dst; codec 0 = zlib / gzip, 1 = Zstandard (libzstd.so.1 loaded on first use), 2 = a Blosc
+ * version-1 frame (zarr v2's default compressor; blosclz / lz4 / zlib / zstd streams, byte or bit shuffle), decoded by hand. */
 int aliby_ingest_inflate(int codec, const void* src, size_t src_bytes, void* dst, size_t dst_bytes,
                          size_t* out_bytes);
 

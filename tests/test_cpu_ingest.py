@@ -282,9 +282,9 @@ def test_image_zarr_v3_and_unsupported_codec(tmp_path):
             path.write_bytes(gzip.compress(block.tobytes(), 2))
     img = im.ImageZarr(source={"path": tmp_path / "s.zarr", "key": "pos"}, capture_order="CYX")
     np.testing.assert_array_equal(np.asarray(img.data)[0, :, 0], a)
-    meta["codecs"][1] = {"name": "blosc", "configuration": {}}
+    meta["codecs"][1] = {"name": "sharding_indexed", "configuration": {}}
     (arr / "zarr.json").write_text(json.dumps(meta))
-    with pytest.raises(NotImplementedError, match="blosc"):
+    with pytest.raises(NotImplementedError, match="sharding_indexed"):
         im.ImageZarr(source={"path": tmp_path / "s.zarr", "key": "pos"}, capture_order="CYX").data
 
 
@@ -298,6 +298,74 @@ def test_inflate_entry_reports_corrupt_streams():
     with pytest.raises(Exception, match="Deflate"):
         _lib.check(lib.aliby_ingest_inflate(0, src.ctypes.data, src.size, out.ctypes.data, out.size, C.byref(got)))
 
+
+
+# ------------------------------------------------------------------------------------- Blosc frames (zarr v2's default compressor)
+BLOSC = Path(__file__).parent / "golden" / "blosc"
+
+
+def _blosc_decode(frame: np.ndarray, room: int):
+    import ctypes as C
+
+    frame = np.ascontiguousarray(frame)
+    out = np.zeros(max(room, 1), np.uint8)
+    got = C.c_size_t(0)
+    _lib.check(_lib.load().aliby_ingest_inflate(2, frame.ctypes.data if frame.size else out.ctypes.data, frame.size, out.ctypes.data, room,
+                                               C.byref(got)))
+    return out[: got.value]
+
+
+def test_blosc_frames_decode_to_the_encoders_input():
+    """Every frame c-blosc 1.21.0 (through imagecodecs, tests/golden/make_blosc_fixtures.py) wrote — blosclz / lz4 / lz4hc / zlib /
+    zstd x no / byte / bit shuffle x item sizes 1, 2, 4 x one and several blocks, compressible, incompressible (memcpyed) and
+    empty inputs — comes back as the bytes that went in.  The decoder (csrc/ingest.hip) shares no code with c-blosc."""
+    n = 0
+    with np.load(BLOSC / "frames.npz") as z:
+        for k in z.files:
+            if k.startswith("f_"):
+                want = z["x_" + k[2:].split("__")[0]]
+                got = _blosc_decode(z[k], want.size)
+                assert got.size == want.size and np.array_equal(got, want), k
+                n += 1
+    assert n >= 150
+
+
+def test_blosc_hostile_frames_are_refused_not_fatal():
+    with np.load(BLOSC / "frames.npz") as z:
+        frame, room = z["f_u16_noisy__lz4__s1__b4096"].copy(), z["x_u16_noisy"].size
+    import struct
+
+    def patched(off, value, fmt="<I"):
+        b = bytearray(frame.tobytes())
+        struct.pack_into(fmt, b, off, value)
+        return np.frombuffer(bytes(b), np.uint8)
+
+    first_block = struct.unpack_from("<I", frame.tobytes(), 16)[0]
+    for bad, why in [(frame[:10], "shorter"), (patched(4, 0xFFFFFFFF), "room"), (patched(8, 0), "block size"), (patched(12, 0xFFFFFFFF), "truncated"),
+                     (patched(16, 0xFFFFFFF0), "past the frame"), (patched(first_block, 0x7FFFFFFF), "past the frame"),
+                     (patched(0, 9, "<B"), "version"), (patched(2, 0x41, "<B"), "codec"), (frame[: frame.size // 2], "truncated")]:
+        with pytest.raises(Exception, match=why):
+            _blosc_decode(bad, room)
+    # a corrupted stream is either refused or decodes to something else: never more than the room it was given
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        b = frame.copy()
+        b[rng.integers(16, b.size, 4)] = rng.integers(0, 256, 4)
+        try:
+            assert _blosc_decode(b, room).size <= room
+        except Exception:
+            pass
+
+
+def test_image_zarr_blosc_group_config5_shape():
+    """ImageZarr (image.py:236-264) over a Blosc-compressed zarr v2 group shaped like BASELINE config 5."""
+    img = im.ImageZarr(source={"path": BLOSC / "c5.zarr", "key": "0"}, capture_order="TCZYX")
+    with np.load(BLOSC / "c5_expected.npz") as z:
+        want = z["pixels"]
+    data = img.get_data_lazy()
+    assert data.shape == want.shape == (1, 2, 8, 128, 160) and img.dimorder == "TCZYX"
+    np.testing.assert_array_equal(np.asarray(data), want)
+    np.testing.assert_array_equal(data[0, 1, 3, 17:90, 5:61], want[0, 1, 3, 17:90, 5:61])
 
 
 # ------------------------------------------------------------------------------------- hostile directory fields

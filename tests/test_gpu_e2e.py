@@ -201,3 +201,42 @@ def test_deep_zstack_projection_config5_like(engine):
     for a, b in zip(res, res_o):
         for k in b:
             assert np.allclose(a[k], b[k], rtol=1e-4, atol=1e-8, equal_nan=True), k
+
+
+def test_config5_from_a_blosc_zarr_group_equals_the_array_source(tmp_path, engine):
+    """BASELINE config 5 as stated: a Zarr-backed Z-stack through the pipeline.  The store is a zarr v2 group with zarr's default
+    compressor (Blosc lz4 + byte shuffle; written by c-blosc in the build container, tests/golden/make_blosc_fixtures.py), opened
+    by ImageZarr (reference: src/aliby/io/image.py:236-264) and decoded by csrc/ingest.hip: profiles and masks come out bit for
+    bit as from the same stack handed over as an array."""
+    from pathlib import Path
+
+    import pyarrow.parquet as pq
+    import torch
+
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    store = Path(__file__).parent / "golden" / "blosc"
+    with np.load(store / "c5_expected.npz") as z:
+        pixels, nuclei = z["pixels"], z["nuclei"]
+    dP, prob = synth.analytic_flows(nuclei)
+
+    def override(x):
+        return torch.from_numpy(dP[None]).cuda(), torch.from_numpy(prob[None]).cuda()
+
+    def pipeline(image_kwargs):
+        p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1], features_to_extract=("intensity", "texture"))
+        p["steps"]["tile"]["image_kwargs"] = image_kwargs
+        p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+        return p
+
+    got, _ = run_pipeline_and_post(pipeline=pipeline({"source": {"path": store / "c5.zarr", "key": "0"}, "capture_order": "TCZYX"}), pipeline_name="zarr", output_path=tmp_path)
+    want, _ = run_pipeline_and_post(pipeline=pipeline({"source": pixels}), pipeline_name="array", output_path=tmp_path)
+    assert got.num_rows == want.num_rows == int(nuclei.max()) > 0 and got.schema.equals(want.schema)
+    for c in got.column_names:
+        a, b = got[c].to_numpy(zero_copy_only=False), want[c].to_numpy(zero_copy_only=False)
+        assert np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")), c
+    assert (tmp_path / "profiles" / "zarr.parquet").read_bytes() == (tmp_path / "profiles" / "array.parquet").read_bytes()
+    with np.load(tmp_path / "steps" / "zarr" / "segment_nuclei" / "0000.npz") as za, np.load(tmp_path / "steps" / "array" / "segment_nuclei" / "0000.npz") as zb:
+        assert np.array_equal(za["arr_0"], zb["arr_0"]) and int(za["arr_0"].max()) == int(nuclei.max())
+    assert pq.read_table(tmp_path / "profiles" / "zarr.parquet").num_columns == got.num_columns
