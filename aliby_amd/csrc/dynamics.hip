@@ -20,6 +20,7 @@
 // Kernel shapes: per-pixel kernels are HBM/L2-bound streaming passes (flow following is an L2-resident
 // gather loop); everything per mask runs as one workgroup per object with its bbox staged in LDS.
 #include "common.h"
+#include <vector>
 
 typedef unsigned short u16;
 typedef unsigned long long u64;
@@ -32,21 +33,51 @@ struct DynShape {
 };
 
 // ---------------------------------------------------------------------------------------------
-// 0. normalised, masked flow field: im = ((mask ? dP : 0) / 5) * (2 / (size-1))
+// 0. one pass over (dP, cellprob): the normalised, masked flow field im = ((mask ? dP : 0) / 5) * (2 / (size-1)) and the
+//    compacted list of foreground pixels (cellprob > thr).  Only ~10-35 % of the pixels are foreground and each follows 200
+//    dependent steps, so everything after this pass that is per followed pixel (end point, temporary label) lives in arrays
+//    indexed by the list position j, not by the pixel: the full-frame int32 passes of rounds 1-2 (pt, M0 and their memsets,
+//    the three-phase first-appearance scan) are gone.  Wave-aggregated append, one global atomic per 4096 pixels; the order
+//    of the list inside a chunk is raster order, the order of the chunks is irrelevant (every consumer is order-free).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_prep_flows(const float* __restrict__ dP, const float* __restrict__ prob, float thr,
-                             DynShape s, float cx, float cy, float* __restrict__ im) {
+#define FG_CHUNK 4096  // pixels per workgroup pass
+__global__ __launch_bounds__(256) void k_prep_compact(const float* __restrict__ dP, const float* __restrict__ prob, float thr,
+                                                      DynShape s, float cx, float cy, float* __restrict__ im,
+                                                      int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int red_i[8];
+  __shared__ int wsum[4];
+  __shared__ int s_base;
   const size_t total = (size_t)s.F * s.P;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t f = i / s.P, p = i % s.P;
-    const bool m = prob[i] > thr;
-    float vy = dP[(f * 2 + 0) * s.P + p], vx = dP[(f * 2 + 1) * s.P + p];
-    vy = m ? vy : 0.0f;
-    vx = m ? vx : 0.0f;
-    vy = vy / 5.0f;
-    vx = vx / 5.0f;
-    im[(f * 2 + 0) * s.P + p] = vy * cy;
-    im[(f * 2 + 1) * s.P + p] = vx * cx;
+  for (size_t c0 = (size_t)blockIdx.x * FG_CHUNK; c0 < total; c0 += (size_t)gridDim.x * FG_CHUNK) {
+    unsigned fgmask = 0;
+#pragma unroll
+    for (int k = 0; k < FG_CHUNK / 256; ++k) {
+      const size_t i = c0 + (size_t)k * 256 + threadIdx.x;
+      const bool m = i < total && prob[i] > thr;
+      fgmask |= (unsigned)m << k;
+      if (i < total) {
+        const size_t f = i / s.P, p = i % s.P;
+        float vy = dP[(f * 2 + 0) * s.P + p], vx = dP[(f * 2 + 1) * s.P + p];
+        vy = m ? vy : 0.0f;
+        vx = m ? vx : 0.0f;
+        vy = vy / 5.0f;
+        vx = vx / 5.0f;
+        im[(f * 2 + 0) * s.P + p] = vy * cy;
+        im[(f * 2 + 1) * s.P + p] = vx * cx;
+      }
+    }
+    const int tot = block_sum_i32(__popc(fgmask), red_i);
+    if (tot == 0) continue;  // block-uniform
+    if (threadIdx.x == 0) s_base = atomicAdd(count, tot);
+    __syncthreads();
+    int base = s_base;
+#pragma unroll
+    for (int k = 0; k < FG_CHUNK / 256; ++k) {
+      const bool fg = (fgmask >> k) & 1u;
+      const int pos = block_compact_slot(fg, base, wsum);
+      if (fg) list[pos] = (int)(c0 + (size_t)k * 256 + threadIdx.x);
+    }
+    __syncthreads();
   }
 }
 
@@ -57,39 +88,10 @@ __device__ __forceinline__ float tap(const float* __restrict__ f, int yy, int xx
 // ---------------------------------------------------------------------------------------------
 // 1. flow following + end-point histogram
 // ---------------------------------------------------------------------------------------------
-// foreground pixels (cellprob > thr) compacted into a list so that flow following runs on full waves: only
-// ~10-35 % of the pixels are foreground and each follows 200 dependent steps.  Wave-aggregated append; the
-// list order is irrelevant (every pixel is independent, the histogram is integer).
-#define FG_CHUNK 4096  // pixels per workgroup pass: one global atomic per 4096 pixels instead of one per wave
-__global__ __launch_bounds__(256) void k_compact_fg(const float* __restrict__ prob, float thr, size_t total,
-                                                    int* __restrict__ list, int* __restrict__ count) {
-  __shared__ int red_i[8];
-  __shared__ int wsum[4];
-  __shared__ int s_base;
-  for (size_t c0 = (size_t)blockIdx.x * FG_CHUNK; c0 < total; c0 += (size_t)gridDim.x * FG_CHUNK) {
-    int n = 0;
-    for (int k = 0; k < FG_CHUNK / 256; ++k) {
-      const size_t i = c0 + (size_t)k * 256 + threadIdx.x;
-      n += (i < total && prob[i] > thr) ? 1 : 0;
-    }
-    const int tot = block_sum_i32(n, red_i);
-    if (tot == 0) continue;  // block-uniform
-    if (threadIdx.x == 0) s_base = atomicAdd(count, tot);
-    __syncthreads();
-    int base = s_base;
-    for (int k = 0; k < FG_CHUNK / 256; ++k) {
-      const size_t i = c0 + (size_t)k * 256 + threadIdx.x;
-      const bool fg = i < total && prob[i] > thr;
-      const int pos = block_compact_slot(fg, base, wsum);
-      if (fg) list[pos] = (int)i;
-    }
-    __syncthreads();
-  }
-}
-
 __global__ __launch_bounds__(256) void k_follow(const float* __restrict__ im, const int* __restrict__ list,
                                                 const int* __restrict__ count, DynShape s, int niter,
-                                                int* __restrict__ pt, int* __restrict__ h1, float* __restrict__ pfinal) {
+                                                int* __restrict__ ptc, int* __restrict__ h1, u64* __restrict__ M1,
+                                                float* __restrict__ pfinal) {
   const int total = *count;
   const int H = s.Y, W = s.X;
   const float sx = (float)(W - 1), sy = (float)(H - 1), Wf = (float)W, Hf = (float)H;
@@ -140,51 +142,69 @@ __global__ __launch_bounds__(256) void k_follow(const float* __restrict__ im, co
     qy = fminf(qy, (float)(H + RPAD - 1));
     qx = fminf(qx, (float)(W + RPAD - 1));
     const int cell = (int)qy * s.XP + (int)qx;
-    pt[i] = cell;
+    ptc[j] = cell;  // (indexed by the list position)
     atomicAdd(&h1[f * s.PP + cell], 1);
+    // the seed-ownership map is only ever looked up at end-point cells: they are cleared here, by whoever ends there, instead of
+    // by a memset of 8 bytes per padded pixel (k_grow's atomicMax runs in a later launch; cells never looked up may hold anything)
+    M1[f * s.PP + cell] = 0ull;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // 2. seeds (5x5 maxima with > 10 points) and their grown masks
 // ---------------------------------------------------------------------------------------------
-__global__ void k_seeds(const int* __restrict__ h1, DynShape s, int* __restrict__ seed_list,
-                        int* __restrict__ seed_count, int seed_cap) {
-  const size_t total = (size_t)s.F * s.PP;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int h = h1[i];
+// Every seed is the end point of at least 11 followed pixels, so the candidates are the end-point cells of the list: the first
+// visitor of a cell (claimed through the histogram word's top bit) tests it, instead of a scan of all padded cells.  Per-tile
+// seed lists (65536 slots each; a tile with more seeds than uint16 labels overflows later anyway and is reported there).
+#define H_MASK 0x7fffffff
+#define SEEDS_PER_TILE 65536
+__global__ __launch_bounds__(256) void k_seeds(const int* __restrict__ list, const int* __restrict__ count, const int* __restrict__ ptc,
+                                               int* __restrict__ h1, DynShape s, int* __restrict__ seed_list, int* __restrict__ seed_count) {
+  const int total = *count;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    const size_t f = (size_t)list[j] / s.P;
+    const int cell = ptc[j];
+    int* hf = h1 + f * s.PP;
+    const int h = hf[cell] & H_MASK;
     if (h <= 10) continue;
-    const size_t f = i / s.PP;
-    const int cell = (int)(i % s.PP), r = cell / s.XP, c = cell % s.XP;
-    const int* hf = h1 + f * s.PP;
+    if (atomicOr(&hf[cell], (int)0x80000000) < 0) continue;  // another pixel with this end point has tested the cell
+    const int r = cell / s.XP, c = cell % s.XP;
     bool ismax = true;
     for (int dr = -2; dr <= 2 && ismax; ++dr)
       for (int dc = -2; dc <= 2; ++dc) {
         const int rr = r + dr, cc = c + dc;
         if (rr < 0 || rr >= s.YP || cc < 0 || cc >= s.XP) continue;
-        if (hf[rr * s.XP + cc] > h) { ismax = false; break; }
+        if ((hf[rr * s.XP + cc] & H_MASK) > h) { ismax = false; break; }
       }
     if (!ismax) continue;
-    const int k = atomicAdd(seed_count, 1);
-    if (k < seed_cap) { seed_list[2 * k] = (int)f; seed_list[2 * k + 1] = cell; }
+    const int k = atomicAdd(&seed_count[f], 1);
+    if (k < SEEDS_PER_TILE) seed_list[f * SEEDS_PER_TILE + k] = cell;
   }
 }
 
 // one wave per seed: 11x11 window, 5 x (3x3 dilation AND h>2); owner = max (points, cell) priority
-__global__ __launch_bounds__(64) void k_grow(const int* __restrict__ h1, DynShape s,
-                                             const int* __restrict__ seed_list, const int* __restrict__ seed_count,
-                                             int seed_cap, u64* __restrict__ M1) {
+__global__ __launch_bounds__(64) void k_grow(const int* __restrict__ h1, DynShape s, const int* __restrict__ seed_list,
+                                             const int* __restrict__ seed_count, u64* __restrict__ M1, int* __restrict__ cnt,
+                                             int* __restrict__ firstpos, int* __restrict__ newid) {
   __shared__ unsigned char ok[121], cur[121], nxt[121];
-  const int n = min(*seed_count, seed_cap);
+  const int f = blockIdx.y;
+  const int n = min(seed_count[f], SEEDS_PER_TILE);
   for (int k = blockIdx.x; k < n; k += gridDim.x) {
-    const int f = seed_list[2 * k], cell = seed_list[2 * k + 1];
+    const int cell = seed_list[(size_t)f * SEEDS_PER_TILE + k];
     const int r0 = cell / s.XP, c0 = cell % s.XP;
     const int* hf = h1 + (size_t)f * s.PP;
+    // the words of this seed's temporary label (its cell + 1): pixel count, first raster position, final id — touched only
+    // at seed cells, so they are initialised here instead of by three memsets of 4 bytes per padded pixel
+    if (threadIdx.x == 0) {
+      cnt[(size_t)f * s.PP + cell] = 0;
+      firstpos[(size_t)f * s.PP + cell] = INT_MAX;
+      newid[(size_t)f * s.PP + cell] = 0;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 121; i += 64) {
       const int rr = r0 - 5 + i / 11, cc = c0 - 5 + i % 11;
       const bool in = rr >= 0 && rr < s.YP && cc >= 0 && cc < s.XP;
-      ok[i] = (in && hf[rr * s.XP + cc] > 2) ? 1 : 0;
+      ok[i] = (in && (hf[rr * s.XP + cc] & H_MASK) > 2) ? 1 : 0;
       cur[i] = (i == 60) ? 1 : 0;
     }
     __syncthreads();
@@ -203,7 +223,7 @@ __global__ __launch_bounds__(64) void k_grow(const int* __restrict__ h1, DynShap
       for (int i = threadIdx.x; i < 121; i += 64) cur[i] = nxt[i];
       __syncthreads();
     }
-    const u64 prio = ((u64)(unsigned)hf[cell] << 32) | (u64)(unsigned)cell;
+    const u64 prio = ((u64)(unsigned)(hf[cell] & H_MASK) << 32) | (u64)(unsigned)cell;
     for (int i = threadIdx.x; i < 121; i += 64) {
       if (!cur[i]) continue;
       const int rr = r0 - 5 + i / 11, cc = c0 - 5 + i % 11;
@@ -213,106 +233,98 @@ __global__ __launch_bounds__(64) void k_grow(const int* __restrict__ h1, DynShap
 }
 
 // ---------------------------------------------------------------------------------------------
-// 3. pixel labels (temporary id = owning seed's cell + 1), sizes and first raster positions
+// 3. pixel labels (temporary id = owning seed's cell + 1), sizes, first raster positions, first-appearance renumbering
 // ---------------------------------------------------------------------------------------------
-__global__ void k_assign(const int* __restrict__ pt, const u64* __restrict__ M1, DynShape s,
-                         unsigned int* __restrict__ M0, int* __restrict__ cnt, int* __restrict__ firstpos) {
-  const size_t total = (size_t)s.F * s.P;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t f = i / s.P;
-    const int p = (int)(i % s.P);
-    const int cell = pt[i];
+__global__ __launch_bounds__(256) void k_assign(const int* __restrict__ list, const int* __restrict__ count, const int* __restrict__ ptc,
+                                                const u64* __restrict__ M1, DynShape s, unsigned int* __restrict__ labc,
+                                                int* __restrict__ cnt, int* __restrict__ firstpos) {
+  const int total = *count;
+  const int rounds = (total + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+  for (int it = 0; it < rounds; ++it) {  // (every lane takes part in the ballots below)
+    const int j = (it * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool live = j < total;
+    size_t f = 0;
+    int p = 0;
     unsigned int lab = 0;
-    if (cell >= 0) {
-      const u64 m = M1[f * s.PP + cell];
+    if (live) {
+      const size_t i = (size_t)list[j];
+      f = i / s.P;
+      p = (int)(i % s.P);
+      const u64 m = M1[f * s.PP + ptc[j]];
       if (m) lab = (unsigned int)((m - 1ull) & 0xFFFFFFFFull) + 1u;
+      labc[j] = lab;
     }
-    M0[i] = lab;
-    // Neighbouring lanes are neighbouring pixels, mostly of the same mask: one atomic pair per RUN of equal labels inside the
-    // wave instead of one per pixel (a ~20-pixel mask row was 20 atomics on one address).  Integer atomics: same result.
+    // Neighbouring lanes are neighbouring foreground pixels of a row, mostly of the same mask: one atomic pair per RUN of equal
+    // labels inside the wave instead of one per pixel.  Integer atomics: same result in any order.
     const int lane = threadIdx.x & (WAVE - 1);
     const unsigned long long key = ((unsigned long long)f << 32) | lab;
     const unsigned long long prev = __shfl_up(key, 1, WAVE);
     const bool head = lab && (lane == 0 || prev != key);
-    // run boundaries: a head, any background lane, any lane past the end of the batch
     const unsigned long long heads = __ballot(head || !lab) | ~__ballot(1);
     if (head) {
       const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
-      const int run = after ? __ffsll((long long)after) : 64 - lane;  // lanes up to the next boundary (or the end of the wave)
+      const int run = after ? __ffsll((long long)after) : 64 - lane;
       atomicAdd(&cnt[f * s.PP + lab - 1], run);
-      atomicMin(&firstpos[f * s.PP + lab - 1], p);  // the head is the run's first raster position
+      atomicMin(&firstpos[f * s.PP + lab - 1], p);  // (the list is in raster order inside a wave: the head is the run's first position)
     }
   }
 }
 
-#define SCAN_BLK 1024
-// flag = pixel is the first raster occurrence of a kept label; phase A: per-block counts
-__global__ __launch_bounds__(256) void k_first_counts(const unsigned int* __restrict__ M0, const int* __restrict__ cnt,
-                                                      const int* __restrict__ firstpos, DynShape s, float big,
-                                                      int nblk, int* __restrict__ blockcnt) {
+// New id of every kept label = 1 + the number of kept labels of its tile that appear earlier in raster order (cellpose renumbers
+// in order of first appearance).  The labels are the tile's seeds (a few hundred): one thread per seed counts the others.
+__global__ __launch_bounds__(256) void k_rank_ids(const int* __restrict__ seed_list, const int* __restrict__ seed_count, DynShape s,
+                                                  const int* __restrict__ cnt, const int* __restrict__ firstpos, float big,
+                                                  int* __restrict__ newid, int* __restrict__ ntot) {
+  __shared__ int tile_pos[1024];
   __shared__ int red_i[8];
-  const int f = blockIdx.y, b = blockIdx.x;
-  int c = 0;
-  for (int k = threadIdx.x; k < SCAN_BLK; k += blockDim.x) {
-    const size_t p = (size_t)b * SCAN_BLK + k;
-    if (p >= s.P) break;
-    const unsigned int lab = M0[(size_t)f * s.P + p];
-    if (lab && firstpos[(size_t)f * s.PP + lab - 1] == (int)p && !((float)cnt[(size_t)f * s.PP + lab - 1] > big)) ++c;
-  }
-  c = block_sum_i32(c, red_i);
-  if (threadIdx.x == 0) blockcnt[(size_t)f * nblk + b] = c;
-}
-
-// phase B: exclusive scan of block counts (one workgroup per tile); total -> ntot[f]
-__global__ __launch_bounds__(1024) void k_scan_blocks(int* __restrict__ blockcnt, int nblk, int* __restrict__ ntot) {
-  __shared__ int part[1024];
-  const int f = blockIdx.x, t = threadIdx.x;
-  int* bc = blockcnt + (size_t)f * nblk;
-  const int per = (nblk + 1023) / 1024;
-  const int lo = min(t * per, nblk), hi = min(lo + per, nblk);
-  int ssum = 0;
-  for (int i = lo; i < hi; ++i) ssum += bc[i];
-  part[t] = ssum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = (t >= o) ? part[t - o] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  int run = part[t] - ssum;
-  for (int i = lo; i < hi; ++i) { const int c = bc[i]; bc[i] = run; run += c; }
-  if (t == 1023) ntot[f] = part[1023];
-}
-
-// phase C: new id of every kept label = 1 + number of first-occurrence pixels before it
-__global__ __launch_bounds__(256) void k_first_ids(const unsigned int* __restrict__ M0, const int* __restrict__ cnt,
-                                                   const int* __restrict__ firstpos, DynShape s, float big, int nblk,
-                                                   const int* __restrict__ blockbase, int* __restrict__ newid) {
-  __shared__ int wsum[4];
-  const int f = blockIdx.y, b = blockIdx.x;
-  int base = blockbase[(size_t)f * nblk + b];
-  for (int k0 = 0; k0 < SCAN_BLK; k0 += blockDim.x) {
-    const size_t p = (size_t)b * SCAN_BLK + k0 + threadIdx.x;
-    bool flag = false;
-    unsigned int lab = 0;
-    if (p < s.P) {
-      lab = M0[(size_t)f * s.P + p];
-      flag = lab && firstpos[(size_t)f * s.PP + lab - 1] == (int)p && !((float)cnt[(size_t)f * s.PP + lab - 1] > big);
+  const int f = blockIdx.x;
+  const int n = min(seed_count[f], SEEDS_PER_TILE);
+  const int* sl = seed_list + (size_t)f * SEEDS_PER_TILE;
+  const size_t base = (size_t)f * s.PP;
+  int kept_total = 0;
+  for (int k0 = 0; k0 < n; k0 += blockDim.x) {
+    const int k = k0 + threadIdx.x;
+    int mine = INT_MAX, cell = 0;
+    bool kept = false;
+    if (k < n) {
+      cell = sl[k];
+      const int c = cnt[base + cell];
+      kept = c > 0 && !((float)c > big);
+      mine = kept ? firstpos[base + cell] : INT_MAX;
     }
-    const int pos = block_compact_slot(flag, base, wsum);
-    if (flag) newid[(size_t)f * s.PP + lab - 1] = pos + 1;
+    int before = 0;
+    for (int q0 = 0; q0 < n; q0 += 1024) {  // the other seeds' first positions, 1024 at a time through LDS
+      __syncthreads();
+      for (int q = threadIdx.x; q < 1024; q += blockDim.x) {
+        int v = INT_MAX;
+        if (q0 + q < n) {
+          const int cq = sl[q0 + q];
+          const int c = cnt[base + cq];
+          if (c > 0 && !((float)c > big)) v = firstpos[base + cq];
+        }
+        tile_pos[q] = v;
+      }
+      __syncthreads();
+      const int m = min(1024, n - q0);
+      if (kept)
+        for (int q = 0; q < m; ++q) before += tile_pos[q] < mine ? 1 : 0;
+    }
+    if (kept) newid[base + cell] = before + 1;
+    kept_total += kept ? 1 : 0;
   }
+  kept_total = block_sum_i32(kept_total, red_i);
+  if (threadIdx.x == 0) ntot[f] = kept_total;
 }
 
-__global__ void k_apply_ids(const unsigned int* __restrict__ M0, const int* __restrict__ newid, DynShape s,
-                            u16* __restrict__ labels) {
-  const size_t total = (size_t)s.F * s.P;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t f = i / s.P;
-    const unsigned int lab = M0[i];
-    int id = lab ? newid[f * s.PP + lab - 1] : 0;
-    labels[i] = (u16)(id > 65535 ? 65535 : id);
+__global__ void k_apply_ids(const int* __restrict__ list, const int* __restrict__ count, const unsigned int* __restrict__ labc,
+                            const int* __restrict__ newid, DynShape s, u16* __restrict__ labels) {
+  const int total = *count;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    const unsigned int lab = labc[j];
+    if (!lab) continue;  // (labels is zero-filled)
+    const size_t i = (size_t)list[j];
+    const int id = newid[(i / s.P) * s.PP + lab - 1];
+    if (id) labels[i] = (u16)(id > 65535 ? 65535 : id);
   }
 }
 
@@ -514,8 +526,21 @@ struct FillArgs {
   const int* newlabel;
   size_t cap_cells;
   unsigned char* gscratch;
-  unsigned int* out32;  // [F,Y,X], zeroed; atomicMax resolves nested holes (highest label wins)
+  u16* out;  // [F,Y,X], zeroed; a 16-bit atomic max resolves nested holes (highest label wins)
 };
+
+// max into one half of an aligned 32-bit word (there are no 16-bit atomics): compare-and-swap until our half is >= v
+__device__ __forceinline__ void atomic_max_u16(u16* addr, unsigned v) {
+  unsigned int* word = reinterpret_cast<unsigned int*>(reinterpret_cast<size_t>(addr) & ~(size_t)3);
+  const unsigned shift = (reinterpret_cast<size_t>(addr) & 2) ? 16u : 0u;
+  unsigned int old = *word;
+  while (((old >> shift) & 0xffffu) < v) {
+    const unsigned int want = (old & ~(0xffffu << shift)) | (v << shift);
+    const unsigned int seen = atomicCAS(word, old, want);
+    if (seen == old) break;
+    old = seen;
+  }
+}
 
 template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_fill(FillArgs a) {
@@ -555,22 +580,27 @@ __global__ __launch_bounds__(256) void k_fill(FillArgs a) {
       __syncthreads();
       if (!any) break;
     }
-    unsigned int* out = a.out32 + (size_t)o.tile * plane;
+    u16* out = a.out + (size_t)o.tile * plane;
     for (int i = tid; i < h * w; i += blockDim.x) {
       const int q = (i / w + 1) * pw + (i % w) + 1;
-      if (st[q] != 2) atomicMax(&out[(size_t)(o.y0 + i / w) * a.X + o.x0 + i % w], (unsigned int)nl);
+      if (st[q] != 2) atomic_max_u16(&out[(size_t)(o.y0 + i / w) * a.X + o.x0 + i % w], (unsigned)nl);
     }
     __syncthreads();
   }
 }
 
-__global__ void k_to_u16(const unsigned int* __restrict__ in, size_t n, u16* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = (u16)in[i];
-}
-
-__global__ void k_fill_int(int* p, size_t n, int v) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+// The heat map Tg is written at mask pixels and read at mask pixels and their four neighbours: zero is needed on every object's
+// box grown by one pixel, not on the whole frame (8 bytes per pixel).  All boxes are cleared before any mask is written.
+__global__ __launch_bounds__(256) void k_zero_boxes(const aliby_object* __restrict__ tab, int n_obj, int Y, int X, double* __restrict__ Tg) {
+  const size_t plane = (size_t)Y * X;
+  for (int oi = blockIdx.x; oi < n_obj; oi += gridDim.x) {
+    const aliby_object o = tab[oi];
+    if (o.area <= 0) continue;
+    const int y0 = max(o.y0 - 1, 0), y1 = min(o.y1 + 1, Y), x0 = max(o.x0 - 1, 0), x1 = min(o.x1 + 1, X);
+    const int w = x1 - x0, n = (y1 - y0) * w;
+    double* T = Tg + (size_t)o.tile * plane;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) T[(size_t)(y0 + i / w) * X + x0 + i % w] = 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -584,16 +614,15 @@ size_t aliby_masks_workspace_bytes(int F, int Y, int X) {
   const size_t P = (size_t)Y * X, PP = (size_t)(Y + 2 * RPAD) * (X + 2 * RPAD);
   size_t b = 0;
   b += align256(sizeof(float) * 2 * P * F);   // im
-  b += align256(sizeof(int) * P * F);         // pt
-  b += align256(sizeof(int) * PP * F) * 3;    // h1/cnt, firstpos, newid
+  b += align256(sizeof(int) * P * F) * 3;     // foreground list, end-point cells, temporary labels (sized for an all-foreground frame)
+  b += align256(sizeof(int) * PP * F) * 4;    // h1, cnt, firstpos, newid
   b += align256(sizeof(u64) * PP * F);        // M1
-  b += align256(sizeof(unsigned) * P * F);    // M0 / out32
+  b += align256(sizeof(u16) * P * F);         // first-appearance labels (before QC)
   b += align256(sizeof(double) * P * F);      // Tg
-  b += align256(sizeof(int) * 2 * 65536 * (size_t)F);  // seed list
-  b += align256(sizeof(int) * ((P + SCAN_BLK - 1) / SCAN_BLK) * F);  // block counts
+  b += align256(sizeof(int) * SEEDS_PER_TILE * (size_t)F);  // seed lists
   b += align256(sizeof(aliby_object) * 65536 * (size_t)F);  // object table
   b += align256(sizeof(int) * 65536 * (size_t)F) * 2;  // bad, newlabel
-  b += align256(sizeof(int) * (size_t)(4 * F + 8));    // counters
+  b += align256(sizeof(int) * (size_t)(5 * F + 8));    // counters
   return b;
 }
 
@@ -614,75 +643,71 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
   DynShape sh;
   sh.F = F; sh.Y = Y; sh.X = X; sh.YP = Y + 2 * RPAD; sh.XP = X + 2 * RPAD;
   sh.P = (size_t)Y * X; sh.PP = (size_t)sh.YP * sh.XP;
-  const int nblk = (int)((sh.P + SCAN_BLK - 1) / SCAN_BLK);
-  ARG_CHECK(sh.PP < (size_t)INT_MAX && F <= 65535 && nblk <= 65535 * 16, "image too large");
+  ARG_CHECK(sh.PP < (size_t)INT_MAX && F <= 65535, "image too large");
 
   unsigned char* w = (unsigned char*)workspace;
   auto take = [&](size_t bytes) { unsigned char* p = w; w += align256(bytes); return p; };
   float* im = (float*)take(sizeof(float) * 2 * sh.P * F);
-  int* pt = (int*)take(sizeof(int) * sh.P * F);
+  int* fg_list = (int*)take(sizeof(int) * sh.P * F);
+  int* ptc = (int*)take(sizeof(int) * sh.P * F);
+  unsigned* labc = (unsigned*)take(sizeof(int) * sh.P * F);
   int* h1 = (int*)take(sizeof(int) * sh.PP * F);
+  int* cnt = (int*)take(sizeof(int) * sh.PP * F);
   int* firstpos = (int*)take(sizeof(int) * sh.PP * F);
   int* newid = (int*)take(sizeof(int) * sh.PP * F);
   u64* M1 = (u64*)take(sizeof(u64) * sh.PP * F);
-  unsigned* M0 = (unsigned*)take(sizeof(unsigned) * sh.P * F);
+  u16* labels_tmp = (u16*)take(sizeof(u16) * sh.P * F);
   double* Tg = (double*)take(sizeof(double) * sh.P * F);
-  const int seed_cap = 65536 * F;
-  int* seed_list = (int*)take(sizeof(int) * 2 * 65536 * (size_t)F);
-  int* blockcnt = (int*)take(sizeof(int) * (size_t)nblk * F);
+  int* seed_list = (int*)take(sizeof(int) * SEEDS_PER_TILE * (size_t)F);
   aliby_object* tab = (aliby_object*)take(sizeof(aliby_object) * 65536 * (size_t)F);
   int* bad = (int*)take(sizeof(int) * 65536 * (size_t)F);
   int* newlabel = (int*)take(sizeof(int) * 65536 * (size_t)F);
-  int* counters = (int*)take(sizeof(int) * (size_t)(4 * F + 8));
-  int* seed_count = counters;
+  int* counters = (int*)take(sizeof(int) * (size_t)(5 * F + 8));
+  int* fg_count = counters + 1;
   int* ntot = counters + 8;          // [F]
   int* niter_tile = ntot + F;        // [F]
   int* nfinal = niter_tile + F;      // [F]
-  int* d_offsets = nfinal + F;       // [F+1] (fits: 4F+8 >= 8+3F+F+1 only if ... see below)
-  (void)d_offsets;
+  int* seed_count = nfinal + F;      // [F]
 
   const size_t totP = sh.P * F, totPP = sh.PP * F;
-  const int gP = (int)((totP + 255) / 256 > 16384 ? 16384 : (totP + 255) / 256);
-  const int gPP = (int)((totPP + 255) / 256 > 16384 ? 16384 : (totPP + 255) / 256);
-
-  HIP_TRY(hipMemsetAsync(h1, 0, sizeof(int) * totPP, s));
-  HIP_TRY(hipMemsetAsync(M1, 0, sizeof(u64) * totPP, s));
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(4 * F + 8), s));
-  const float cx = 2.0f / (float)(X - 1), cy = 2.0f / (float)(Y - 1);
-  hipLaunchKernelGGL(k_prep_flows, dim3(gP), dim3(256), 0, s, dP, cellprob, cellprob_threshold, sh, cx, cy, im);
-  KERNEL_CHECK();
   ARG_CHECK(totP < (size_t)INT_MAX, "batch too large for 32-bit pixel indices");
-  int* fg_list = newid;            // free until the renumbering step
-  int* fg_count = counters + 1;
-  HIP_TRY(hipMemsetAsync(pt, 0xFF, sizeof(int) * totP, s));  // -1 = background
-  hipLaunchKernelGGL(k_compact_fg, dim3(gP), dim3(256), 0, s, cellprob, cellprob_threshold, totP, fg_list, fg_count);
+  const int gP = (int)((totP + 255) / 256 > 16384 ? 16384 : (totP + 255) / 256);
+
+  // Memsets: the end-point histogram (read in 5x5 / 11x11 neighbourhoods: it must be zero everywhere), the two label images
+  // (written at foreground pixels only) and the counters.  Everything else that rounds 1-2 cleared per padded pixel — the seed
+  // map M1, the per-label count / first position / new id words — is initialised where it is used (k_follow, k_grow).
+  HIP_TRY(hipMemsetAsync(h1, 0, sizeof(int) * totPP, s));
+  HIP_TRY(hipMemsetAsync(labels_tmp, 0, sizeof(u16) * totP, s));
+  HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(u16) * totP, s));
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(5 * F + 8), s));
+  const float cx = 2.0f / (float)(X - 1), cy = 2.0f / (float)(Y - 1);
+  hipLaunchKernelGGL(k_prep_compact, dim3(gP), dim3(256), 0, s, dP, cellprob, cellprob_threshold, sh, cx, cy, im, fg_list, fg_count);
   KERNEL_CHECK();
-  hipLaunchKernelGGL(k_follow, dim3(gP), dim3(256), 0, s, im, fg_list, fg_count, sh, niter, pt, h1, p_final_out);
+  hipLaunchKernelGGL(k_follow, dim3(gP), dim3(256), 0, s, im, fg_list, fg_count, sh, niter, ptc, h1, M1, p_final_out);
   KERNEL_CHECK();
-  hipLaunchKernelGGL(k_seeds, dim3(gPP), dim3(256), 0, s, h1, sh, seed_list, seed_count, seed_cap);
+  hipLaunchKernelGGL(k_seeds, dim3(gP), dim3(256), 0, s, fg_list, fg_count, ptc, h1, sh, seed_list, seed_count);
   KERNEL_CHECK();
-  hipLaunchKernelGGL(k_grow, dim3(4096), dim3(64), 0, s, h1, sh, seed_list, seed_count, seed_cap, M1);
+  hipLaunchKernelGGL(k_grow, dim3(256, F), dim3(64), 0, s, h1, sh, seed_list, seed_count, M1, cnt, firstpos, newid);
   KERNEL_CHECK();
-  // h1 is free now: reuse as per-label pixel counts
-  int* cnt = h1;
-  HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * totPP, s));
-  hipLaunchKernelGGL(k_fill_int, dim3(gPP), dim3(256), 0, s, firstpos, totPP, INT_MAX);
-  KERNEL_CHECK();
-  hipLaunchKernelGGL(k_assign, dim3(gP), dim3(256), 0, s, pt, M1, sh, M0, cnt, firstpos);
+  hipLaunchKernelGGL(k_assign, dim3(gP), dim3(256), 0, s, fg_list, fg_count, ptc, M1, sh, labc, cnt, firstpos);
   KERNEL_CHECK();
   const float big = (float)((double)Y * (double)X * (double)max_size_fraction);
-  hipLaunchKernelGGL(k_first_counts, dim3(nblk, F), dim3(256), 0, s, M0, cnt, firstpos, sh, big, nblk, blockcnt);
+  hipLaunchKernelGGL(k_rank_ids, dim3(F), dim3(256), 0, s, seed_list, seed_count, sh, cnt, firstpos, big, newid, ntot);
   KERNEL_CHECK();
-  hipLaunchKernelGGL(k_scan_blocks, dim3(F), dim3(1024), 0, s, blockcnt, nblk, ntot);
-  KERNEL_CHECK();
-  HIP_TRY(hipMemsetAsync(newid, 0, sizeof(int) * totPP, s));
-  hipLaunchKernelGGL(k_first_ids, dim3(nblk, F), dim3(256), 0, s, M0, cnt, firstpos, sh, big, nblk, blockcnt, newid);
-  KERNEL_CHECK();
-  hipLaunchKernelGGL(k_apply_ids, dim3(gP), dim3(256), 0, s, M0, newid, sh, labels_out);
+  hipLaunchKernelGGL(k_apply_ids, dim3(gP), dim3(256), 0, s, fg_list, fg_count, labc, newid, sh, labels_tmp);
   KERNEL_CHECK();
   HIP_TRY(hipMemcpyAsync(n_labels_host, ntot, sizeof(int) * F, hipMemcpyDeviceToHost, s));
   { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   int n_obj = 0;
+  {
+    std::vector<int> nseeds((size_t)F);
+    HIP_TRY(hipMemcpy(nseeds.data(), seed_count, sizeof(int) * F, hipMemcpyDeviceToHost));  // (the stream is idle: just waited)
+    for (int f = 0; f < F; ++f)
+      if (nseeds[f] >= SEEDS_PER_TILE - 1) {
+        aliby_set_error("Segmentation produced %d seeds in one tile; uint16 cast unsafe.", nseeds[f]);
+        return ALIBY_ERR_OVERFLOW;
+      }
+  }
   for (int f = 0; f < F; ++f) {
     if (n_labels_host[f] >= 65535) {
       aliby_set_error("Segmentation produced %d labels; uint16 cast unsafe.", n_labels_host[f]);
@@ -690,14 +715,14 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
     }
     n_obj += n_labels_host[f];
   }
-  if (n_obj == 0) return ALIBY_OK;  // labels_out is already all zero
+  if (n_obj == 0) return ALIBY_OK;  // labels_out is all zero
 
   // ---- per-mask stages: object table, flow QC, hole fill ----------------------------------------
   int* offsets = new int[F + 1];
   offsets[0] = 0;
   for (int f = 0; f < F; ++f) offsets[f + 1] = offsets[f] + n_labels_host[f];
   aliby_object* tab_host = new aliby_object[n_obj];
-  int rc = aliby_object_table(ctx, labels_out, F, Y, X, offsets, tab, tab_host, stream);
+  int rc = aliby_object_table(ctx, labels_tmp, F, Y, X, offsets, tab, tab_host, stream);
   if (rc) { delete[] offsets; delete[] tab_host; return rc; }
   int max_h = 0, max_w = 0;
   int* nit = new int[F];
@@ -718,9 +743,10 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
   const size_t cells = ((size_t)(max_h + 2) * (max_w + 2) + 15) & ~(size_t)15;
 
   if (flow_threshold > 0.0f) {
-    HIP_TRY(hipMemsetAsync(Tg, 0, sizeof(double) * totP, s));
+    hipLaunchKernelGGL(k_zero_boxes, dim3(n_obj < 8192 ? n_obj : 8192), dim3(256), 0, s, tab, n_obj, Y, X, Tg);
+    KERNEL_CHECK();
     QcArgs q;
-    q.labels = labels_out; q.dP = dP; q.F = F; q.Y = Y; q.X = X; q.tab = tab; q.n_obj = n_obj;
+    q.labels = labels_tmp; q.dP = dP; q.F = F; q.Y = Y; q.X = X; q.tab = tab; q.n_obj = n_obj;
     q.niter_tile = niter_tile; q.cap_cells = cells; q.Tg = Tg;
     const size_t need = cells * 17;
     if (need <= 128 * 1024) {
@@ -748,12 +774,10 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
   }
   hipLaunchKernelGGL(k_final_ids, dim3(F), dim3(1024), 0, s, tab, d_off, bad, min_size, newlabel, nfinal);
   KERNEL_CHECK();
-  unsigned* out32 = M0;
-  HIP_TRY(hipMemsetAsync(out32, 0, sizeof(unsigned) * totP, s));
   {
     FillArgs fa;
-    fa.labels = labels_out; fa.F = F; fa.Y = Y; fa.X = X; fa.tab = tab; fa.n_obj = n_obj; fa.newlabel = newlabel;
-    fa.cap_cells = cells; fa.out32 = out32;
+    fa.labels = labels_tmp; fa.F = F; fa.Y = Y; fa.X = X; fa.tab = tab; fa.n_obj = n_obj; fa.newlabel = newlabel;
+    fa.cap_cells = cells; fa.out = labels_out;
     if (cells <= 128 * 1024) {
       fa.gscratch = nullptr;
       if (cells > 32 * 1024)
@@ -769,8 +793,6 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
     }
     KERNEL_CHECK();
   }
-  hipLaunchKernelGGL(k_to_u16, dim3(gP), dim3(256), 0, s, out32, totP, labels_out);
-  KERNEL_CHECK();
   HIP_TRY(hipMemcpyAsync(n_labels_host, nfinal, sizeof(int) * F, hipMemcpyDeviceToHost, s));
   { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
   delete[] offsets;

@@ -40,7 +40,7 @@ def masks_from_flows(eng, dP, cellprob, niter=200, cellprob_threshold=0.0, flow_
     cellprob = cellprob.contiguous()
     F, two, Y, X = dP.shape
     assert two == 2 and tuple(cellprob.shape) == (F, Y, X)
-    labels = torch.zeros((F, Y, X), dtype=torch.uint16, device=dP.device)
+    labels = torch.empty((F, Y, X), dtype=torch.uint16, device=dP.device)  # (cleared by the library)
     n = np.zeros(max(F, 1), np.int32)
     ws, need = _workspace(eng.lib, F, Y, X, dP.device)
     pf = torch.zeros((F, 2, Y, X), dtype=torch.float32, device=dP.device) if return_endpoints else None
