@@ -51,6 +51,8 @@ if files:
     def grp(k):
         if k.startswith("k_conv_pair32"):
             return "conv3x3_mfma_pair"
+        if k.startswith("k_conv_first_pair"):
+            return "conv3x3_mfma_first_pair"
         if k.startswith("k_conv3x3_deep"):
             return "conv3x3_mfma_deep"
         if k.startswith("k_conv3x3"):
@@ -91,6 +93,8 @@ for which, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 def conv_group(k):  # same split as fused_unet._launch_unit / _unit_head: 128-output-channel launches are the compute-bound group
     if k.startswith("k_conv_pair32"):
         return "conv3x3_mfma_pair"
+    if k.startswith("k_conv_first_pair"):
+        return "conv3x3_mfma_first_pair"
     if not k.startswith("k_conv3x3"):
         return None
     if k.startswith("k_conv3x3_deep"):
@@ -103,6 +107,7 @@ def conv_group(k):  # same split as fused_unet._launch_unit / _unit_head: 128-ou
 
 groups = {"conv3x3_mfma": lambda k: conv_group(k) == "conv3x3_mfma", "conv3x3_mfma_deep": lambda k: conv_group(k) == "conv3x3_mfma_deep",
           "conv3x3_mfma_head": lambda k: conv_group(k) == "conv3x3_mfma_head", "conv3x3_mfma_pair": lambda k: conv_group(k) == "conv3x3_mfma_pair",
+          "conv3x3_mfma_first_pair": lambda k: conv_group(k) == "conv3x3_mfma_first_pair",
           "fused_pointwise": lambda k: k.startswith("k_fused_act"), "out_head": lambda k: k.startswith("k_out_head"),
           "conv1x1_mfma": lambda k: k.startswith("k_conv1x1"), "first_conv": lambda k: k.startswith("k_first_conv")}
 out = {}
