@@ -135,6 +135,8 @@ _SIGNATURES = {
     "aliby_features_cell": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "aliby_features_coloc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i,
                                   C.c_double, C.c_double, _vp, _vp, _vp]),
+    "aliby_labels_apply_lut": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "aliby_features_intensity3d": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "aliby_parquet_write": (_i, [C.c_char_p, _vp, _i, _vp, _i, _vp, _vp, _i]),
     "aliby_npz_write": (_i, [C.c_char_p, _vp, _i, _i]),
     "aliby_host_codecs": (_i, [C.POINTER(_i), C.POINTER(_i)]),

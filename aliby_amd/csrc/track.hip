@@ -10,7 +10,8 @@
 // MI355X shape: the (N_cur x N_prev) overlap matrix is never formed.  One workgroup per current object scans its
 // bounding box once and counts the previous labels under its mask in a small LDS hash table (integer atomics), so the
 // two label planes are read once (HBM-bound, 2·P·2 bytes per tile); at most floor(1/threshold) previous objects can
-// pass the threshold for one current object, so candidates fit a fixed 8-slot list.  Column maxima are one 64-bit
+// pass the threshold for one current object; candidates go to a fixed 16-slot list (more than 16 previous objects above the
+// threshold under one mask — only possible for thresholds below 1/16 — is reported as an error, never dropped silently).  Column maxima are one 64-bit
 // integer atomicMax per candidate on the bit pattern of the (positive) double.  New labels are handed out in current
 // label order by one workgroup per tile.
 #include "common.h"
@@ -18,7 +19,7 @@
 typedef unsigned short u16;
 
 #define TRK_SLOTS 1024  // LDS hash slots per object (distinct previous labels under one mask)
-#define TRK_K 8         // candidates kept per current object: needs threshold >= 1/8
+#define TRK_K 16        // candidates kept per current object (a 17th previous object above the threshold under one mask is reported)
 
 struct TrackArgs {
   const u16* prev;
@@ -140,7 +141,7 @@ extern "C" int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const ui
                                   int32_t* cur_tracked_dev, int32_t* max_label_out_host, void* stream) {
   ARG_CHECK(ctx && cur_offsets_host && prev_offsets_host && max_label_out_host, "NULL argument");
   ARG_CHECK(F > 0 && Y > 0 && X > 0, "bad shape");
-  ARG_CHECK(threshold >= 1.0 / TRK_K && threshold <= 1.0, "stitch threshold must lie in [1/8, 1]");
+  ARG_CHECK(threshold >= 0.01 && threshold <= 1.0, "stitch threshold must lie in [0.01, 1]");
   const int n_cur = cur_offsets_host[F], n_prev = prev_offsets_host[F];
   ARG_CHECK(n_cur >= 0 && n_prev >= 0 && cur_offsets_host[0] == 0 && prev_offsets_host[0] == 0, "offsets must be exclusive prefix sums");
   ARG_CHECK(n_cur == 0 || (cur && prev && cur_table_dev && cur_tracked_dev), "NULL argument");
@@ -188,6 +189,52 @@ extern "C" int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const ui
   if (over) {
     aliby_set_error("track_stitch: more than %d previous objects under one current object", over == 1 ? TRK_SLOTS : TRK_K);
     return ALIBY_ERR_TOO_LARGE;
+  }
+  return ALIBY_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Labels through a per-object table: out[t, p] = lut[offsets[t] + in[t, p] - 1] (0 stays 0).  Used to write the stitched
+// (tracked) labels of a Z-stack's planes back into the planes (the do_3D branch of the segmenter, segment/dispatch.py).
+__global__ void k_apply_lut(const u16* __restrict__ in, size_t plane, int T, const int* __restrict__ offsets,
+                            const int* __restrict__ lut, u16* __restrict__ out, int* __restrict__ over) {
+  const size_t total = plane * (size_t)T;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned lb = in[i];
+    unsigned v = 0;
+    if (lb) {
+      const int t = (int)(i / plane);
+      const int row = offsets[t] + (int)lb - 1;
+      const int m = row < offsets[t + 1] ? lut[row] : 0;
+      if (m >= 65535) { *over = m; v = 65535; } else v = (unsigned)(m > 0 ? m : 0);
+    }
+    out[i] = (u16)v;
+  }
+}
+
+extern "C" int aliby_labels_apply_lut(aliby_ctx* ctx, const uint16_t* labels_in, int T, int Y, int X, const int32_t* offsets_host,
+                                      const int32_t* lut_dev, uint16_t* labels_out, void* stream) {
+  ARG_CHECK(ctx && labels_in && labels_out && offsets_host, "NULL argument");
+  ARG_CHECK(T > 0 && Y > 0 && X > 0 && offsets_host[0] == 0 && offsets_host[T] >= 0, "bad shape / offsets");
+  ARG_CHECK(offsets_host[T] == 0 || lut_dev, "NULL table");
+  hipStream_t s = as_stream(stream);
+  int rc = aliby_ensure_scratch(ctx, sizeof(int) * (size_t)(T + 2));
+  if (rc) return rc;
+  int* d_off = (int*)ctx->scratch;
+  int* d_over = d_off + (T + 1);
+  HIP_TRY(hipMemcpyAsync(d_off, offsets_host, sizeof(int) * (size_t)(T + 1), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(int), s));
+  const size_t total = (size_t)T * Y * X;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(k_apply_lut, dim3(grid), dim3(256), 0, s, labels_in, (size_t)Y * X, T, d_off, lut_dev, labels_out, d_over);
+  KERNEL_CHECK();
+  int over = 0;
+  HIP_TRY(hipMemcpyAsync(&over, d_over, sizeof(int), hipMemcpyDeviceToHost, s));
+  { const int rcw = aliby_wait_stream(s); if (rcw) return rcw; }
+  if (over) {
+    aliby_set_error("Segmentation produced %d labels; uint16 cast unsafe.", over);
+    return ALIBY_ERR_OVERFLOW;
   }
   return ALIBY_OK;
 }

@@ -257,6 +257,60 @@ class FeatureEngine:
                 float(threshold), _ptr(tracked), _ptr(mx_out), _stream_ptr()))
         return tracked[: cur_table.n_obj], mx_out
 
+    # ----------------------------------------------------------------- Z-stacks as volumes (round 3 extension, BASELINE config 5)
+    def stitch_planes(self, planes: torch.Tensor, counts=None, threshold: float = 0.01):
+        """Per-plane label images of Z-stacks, uint16 [F,Z,Y,X] with labels 1..n per plane, -> (volume labels uint16 [F,Z,Y,X],
+        objects per stack int32 [F]): cellpose's `stitch3D` along Z (the reference's do_3D branch passes stitch_threshold = 0.01,
+        segment/dispatch.py:193-198) — plane z + 1 is stitched to the already stitched plane z by IoU (aliby_track_stitch, all F
+        stacks per call), new labels continue from the stack's running maximum — then written back through a per-object table."""
+        F, Z, Y, X = planes.shape
+        zf = planes.permute(1, 0, 2, 3).contiguous()  # [Z,F,Y,X]: the planes of one z are consecutive tiles
+        table = self.object_table(zf.view(Z * F, Y, X))
+        off = table.offsets
+        lut = torch.zeros(max(table.n_obj, 1), dtype=torch.int32, device=planes.device)
+        # the stitcher takes F tiles per call: a row's tile index z * F + f becomes f (rows are 8 int32: tile, label, box, area)
+        tab = table.dev.view(torch.int32).view(-1, 8).clone()
+        tab[:, 0].remainder_(F)
+
+        def rows(z):  # (table rows, rebased offsets) of the F planes at depth z
+            lo, hi = int(off[z * F]), int(off[(z + 1) * F])
+            return tab[lo: max(hi, lo + 1)], np.ascontiguousarray(off[z * F: (z + 1) * F + 1] - lo), lo, hi
+
+        d0, o0, lo, hi = rows(0)
+        if hi > lo:  # plane 0 keeps its own labels
+            own = np.concatenate([np.arange(1, int(o0[f + 1] - o0[f]) + 1, dtype=np.int32) for f in range(F)]) if hi > lo else np.zeros(0, np.int32)
+            lut[lo:hi] = torch.from_numpy(own).to(lut.device)
+        mx = np.asarray([int(o0[f + 1] - o0[f]) for f in range(F)], np.int32)
+        prev_rows, prev_off, prev_lo, prev_hi = d0, o0, lo, hi
+        for z in range(1, Z):
+            cur_rows, cur_off, lo, hi = rows(z)
+            tracked = lut[lo: max(hi, lo + 1)]
+            mx_out = np.zeros(F, np.int32)
+            _lib.check(self.lib.aliby_track_stitch(
+                self.ctx.handle, _ptr(zf[z - 1]), _ptr(zf[z]), F, Y, X, _ptr(cur_rows), _ptr(cur_off), _ptr(prev_rows), _ptr(prev_off),
+                _ptr(lut[prev_lo: max(prev_hi, prev_lo + 1)]), _ptr(np.ascontiguousarray(mx)), float(threshold), _ptr(tracked), _ptr(mx_out),
+                _stream_ptr()))
+            mx = mx_out
+            prev_rows, prev_off, prev_lo, prev_hi = cur_rows, cur_off, lo, hi
+        out = torch.empty_like(zf)
+        _lib.check(self.lib.aliby_labels_apply_lut(self.ctx.handle, _ptr(zf), Z * F, Y, X, _ptr(np.ascontiguousarray(off)), _ptr(lut), _ptr(out),
+                                                   _stream_ptr()))
+        return out.permute(1, 0, 2, 3).contiguous(), mx
+
+    def intensity3d(self, volume: torch.Tensor, pixels: torch.Tensor, channel: int, counts) -> torch.Tensor:
+        """Volume labels uint16 [F,Z,Y,X] (1..counts[f] per stack), pixels uint16 [F,C,Z,Y,X] -> float64 [sum counts, 12]
+        (features.intensity3d_names(); aliby_features_intensity3d).  Rows in (stack, label) order."""
+        F, Z, Y, X = volume.shape
+        assert pixels.dtype == torch.uint16 and tuple(pixels.shape[:1]) == (F,) and tuple(pixels.shape[2:]) == (Z, Y, X)
+        offsets = np.zeros(F + 1, np.int32)
+        np.cumsum(np.asarray(counts, np.int32), out=offsets[1:])
+        out = self.new_output(int(offsets[-1]), 12)
+        with self.timed("intensity3d"):
+            _lib.check(self.lib.aliby_features_intensity3d(self.ctx.handle, _ptr(volume.contiguous()), _ptr(pixels.contiguous()), F, pixels.shape[1], Z, Y,
+                                                           X, int(channel), _ptr(offsets), _ptr(out), out.stride(0) if out.numel() else 12, 0,
+                                                           _stream_ptr()))
+        return out
+
     def relabel_sequential(self, labels: torch.Tensor) -> np.ndarray:
         F, Y, X = labels.shape
         n = np.zeros(F, np.int32)

@@ -167,3 +167,11 @@ def family_names(family: str, **kw) -> list[str]:
     if family in COLOC:
         return list(COLOC[family])
     raise KeyError(family)
+
+
+def intensity3d_names() -> list[str]:
+    """Round-3 extension (a Z-stack measured as a volume; beyond what the reference wires): the moment-based
+    statistics of CellProfiler's MeasureObjectIntensity on volumes, named as cp_measure's 2-D `intensity` names them."""
+    return ["Volume", "Intensity_IntegratedIntensity", "Intensity_MeanIntensity", "Intensity_StdIntensity", "Intensity_MinIntensity",
+            "Intensity_MaxIntensity", "Location_CenterMassIntensity_X", "Location_CenterMassIntensity_Y", "Location_CenterMassIntensity_Z",
+            "Location_Center_X", "Location_Center_Y", "Location_Center_Z"]

@@ -250,7 +250,7 @@ class CellposeModel:
         """x: uint16 [F,Y,X] (device tensor or host array) -> (masks, flows, styles) like cellpose.
         masks is a device uint16 tensor, [Y,X] when F == 1 ("Cellpose squeezes dims"), else [F,Y,X]."""
         if do_3D:
-            raise NotImplementedError("do_3D is not wired by the reference pipeline (SURVEY §8d, C5 note)")
+            raise NotImplementedError("do_3D: hand the planes of the stack to eval as a batch and stitch them (segment/dispatch.py does)")
         if not isinstance(x, torch.Tensor):
             x = np.ascontiguousarray(x)
             x = torch.from_numpy(x if x.dtype == np.uint16 else x.astype(np.uint16 if x.dtype in (np.uint8, np.bool_) else np.float32))
@@ -258,7 +258,12 @@ class CellposeModel:
         if x.ndim == 2:
             x = x[None]
         if isinstance(normalize, dict):
-            raise NotImplementedError("normalize={...} (cellpose's per-option dict) is not built: True or False")
+            # cellpose's option dict: the reference passes dict(norm3D=False) on its 3-D branch (dispatch.py:196) = every plane
+            # normalised on its own, which is what a batch of planes gets here.  Anything else in the dict is not built.
+            other = {k: v for k, v in normalize.items() if not (k == "norm3D" and v is False) and not (k == "normalize" and v is True)}
+            if other:
+                raise NotImplementedError(f"normalize options {other} are not built (norm3D=False / normalize=True are)")
+            normalize = True
         dP = prob = None
         if self.flows_override is None or self.run_network_with_override:
             dP, prob = self.run_network(x, normalize=bool(normalize))

@@ -123,9 +123,30 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         if pixels.ndim > 5:
             pixels = pixels[0]
         if do_3D and z_size > 1:
-            raise NotImplementedError("3-D Cellpose (do_3D) is beyond what the pipeline wires (SURVEY §8d C5 note)")
+            return _segment_volume(pixels, dict(kw))
         stack, counts = _labels_of([_device_block(pixels)], dict(kw))
         return _finish(stack, counts)
+
+    def _segment_volume(pixels, kw):
+        """The reference's do_3D branch (dispatch.py:193-198, 216-223): the stack goes to the model with z_axis = 1,
+        stitch_threshold = 0.01, normalize = dict(norm3D=False); whatever 3-D labels come back are collapsed with max(axis=0) and
+        relabelled, so the step's result is 2-D again.  Here (round 3, an extension — cellpose itself is not vendored and its
+        do_3D mode, flows from three orthogonal passes, is not built): every plane is segmented as a 2-D image (normalised on its
+        own = norm3D False), the planes are stitched along Z by IoU >= 0.01 (cellpose's stitch3D rule, aliby_track_stitch), and
+        the volume labels are kept on `segment.last_volume` = (uint16 device tensor [F,Z,Y,X], objects per stack) for 3-D
+        features (FeatureEngine.intensity3d) before the reference's collapse."""
+        import torch
+
+        block = _device_block(pixels)  # [F,C,Z,Y,X]
+        F, _, Z, Y, X = block.shape
+        planes = block[:, channel_to_segment].reshape(F * Z, Y, X).contiguous()
+        kw.pop("normalize", None)
+        result = model.eval(planes, do_3D=False, stitch_threshold=0.0, normalize=dict(norm3D=False), z_axis=None, **kw)
+        labels = result[0] if result[0].ndim == 3 else result[0][None]
+        volume, counts = model.eng.stitch_planes(labels.view(F, Z, Y, X), threshold=0.01)
+        segment.last_volume = (volume, counts)
+        out = [_finish(volume[f], np.asarray([counts[f]])) for f in range(F)]
+        return out[0] if F == 1 else out
 
     def segment_batch(blocks, pinned_alloc=None, **kw):
         """Position-batched form used by aliby_amd.runner: `blocks` = one FCZYX block per position (device tensors or host

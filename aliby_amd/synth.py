@@ -165,6 +165,27 @@ def make_fov(config: int, fov: int = 0, shape=None, n_channels=None, n_z=None, n
     return dict(pixels=pixels, nuclei=nuclei, cells=cells, params=params)
 
 
+def ellipsoid_planes(labels, n_z: int, seed: int = 0):
+    """Per-plane label images [Z,Y,X] of ellipsoids whose mid-plane cross-sections are the objects of `labels` [Y,X]: object k
+    sits at depth zc_k with half-height az_k and its section shrinks towards its poles (normalised in-plane radius <=
+    sqrt(1 - ((z - zc) / az)^2)).  Planes keep the object ids of `labels` (an object is simply absent above and below its
+    poles), which is what a 3-D ground truth looks like; each plane relabelled on its own is what a per-plane segmenter sees."""
+    rng = np.random.default_rng(seed)
+    n = int(labels.max())
+    dist_in = ndimage.distance_transform_edt(labels > 0)
+    rmax = np.maximum(ndimage.maximum(dist_in, labels, np.arange(n + 1)), 1.0)
+    r = np.where(labels > 0, 1.0 - dist_in / rmax[labels], 2.0)  # 0 at the centre, ~1 at the rim
+    zc = np.concatenate([[0.0], rng.uniform(0.25 * n_z, 0.75 * n_z, n)])
+    az = np.concatenate([[1.0], rng.uniform(max(1.5, 0.1 * n_z), max(2.5, 0.3 * n_z), n)])
+    out = np.zeros((n_z, *labels.shape), labels.dtype)
+    for z in range(n_z):
+        t = 1.0 - ((z - zc) / az) ** 2
+        lim = np.sqrt(np.clip(t, 0.0, None))
+        keep = (labels > 0) & (t[labels] > 0) & (r <= lim[labels])
+        out[z] = np.where(keep, labels, 0)
+    return out
+
+
 def write_tiff(path, plane: np.ndarray, compression: str | None = None, rows_per_strip: int = 64) -> None:
     """Minimal little-endian baseline TIFF writer (one 2-D grayscale page; no compression or Deflate) so that
     synthetic stacks can be laid out on disk the way a microscope leaves them, one file per (t, c, z) plane."""

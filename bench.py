@@ -220,6 +220,75 @@ def rehearse(args):
         dist.destroy_process_group()
 
 
+def build_rooflines(prof, model, args, B, C, Z, Y, X, n_obj, n_tiles_net, steps):
+    """The roofline objects of a bench line from the per-group HIP-event timings (`prof`): the dominant hand-written group against
+    HBM peak (algorithmic bytes per launch / average launch time), the deep K-loop conv group against the dense MFMA peak, every
+    group's HBM fraction, and the whole network's rate."""
+    class _T:  # (the code below was written against `table.n_obj`)
+        pass
+
+    table = _T()
+    table.n_obj = n_obj
+    roof = roof_deep = None
+    fracs = {}
+    if prof:  # (--no-kernel-timing: nothing was bracketed)
+        # ---- roofline of the dominant hand-written kernel group ----------------------------------------------
+        hip_groups = {k: v for k, v in prof.items() if k not in ("unet_forward", "rows_d2h")}
+        dominant = max(hip_groups, key=lambda k: hip_groups[k]["ms_total"])
+        launches = hip_groups[dominant]["launches"]
+        avg_ms = hip_groups[dominant]["ms_total"] / launches
+        ab = alg_bytes(dominant, B, C, Z, Y, X, table.n_obj, n_tiles_net)
+        timed_launches = hip_groups[dominant].get("timed_launches", launches)
+        if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the timed launches
+            ab = model.fused.bytes_moved / timed_launches
+        if dominant.startswith("conv3x3_mfma"):  # exact: input + residual read once, output (+ pooled) written once, per timed launch
+            ab = model.fused.conv_stats[dominant][0] / timed_launches
+        achieved = ab / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+        # FETCH_SIZE doubled on gfx950): measured offline, committed under profiles/, see profiles/pmc_traffic.json
+        traffic = None
+        pmc_file = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc_file.exists():
+            traffic = json.loads(pmc_file.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
+                "avg_launch_ms": round(avg_ms, 4), "launches": launches}
+        if dominant.startswith("conv3x3_mfma"):  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
+            roof["mfma_tflops"] = round(model.fused.conv_stats[dominant][1] / timed_launches / (avg_ms * 1e-3) / 1e12, 1)
+        roof["timed_launches"] = timed_launches
+        # the deep levels' launches of the same kernel (128+ output channels): bound by the matrix cores
+        if "conv3x3_mfma_deep" in prof and prof["conv3x3_mfma_deep"].get("timed_launches"):
+            g = prof["conv3x3_mfma_deep"]
+            st = model.fused.conv_stats["conv3x3_mfma_deep"]
+            t_ms = g["ms_total"] / g["launches"]
+            tf = st[1] / g["timed_launches"] / (t_ms * 1e-3) / 1e12
+            roof_deep = {"bound": "mfma", "kernel": "conv3x3_mfma_deep", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(t_ms, 4), "launches": g["launches"],
+                         "timed_launches": g["timed_launches"],
+                         "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
+        # every HBM-bound group's fraction of the 8 TB/s peak: algorithmic bytes per launch / average launch time
+        for name, g in hip_groups.items():
+            if name.startswith("conv") or name in ("first_conv", "style", "out_head", "fused_pointwise"):
+                st = model.fused.conv_stats.get(name) if model.fused is not None else None
+                if not st or not g.get("timed_launches"):
+                    continue
+                gb = st[0] / g["timed_launches"]
+            else:
+                gb = alg_bytes(name, B, C, Z, Y, X, table.n_obj, n_tiles_net)
+            ms = g["ms_total"] / max(g["launches"], 1)
+            if ms > 0:
+                fracs[name] = round(gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(steps, 1)
+    hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "conv3x3_mfma_head", "conv3x3_mfma_pair", "conv3x3_mfma_first_pair", "maxpool", "out_head",
+                                                                       "first_conv", "conv1x1_mfma", "style")) / max(steps, 1)
+    net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
+    mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,
+            "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3,
+            "path": "hand-written HIP (libaliby_hip.so)" if model.fused is not None else "torch module (MIOpen) - A/B reference, not the product path"}
+
+    return roof, roof_deep, fracs, mfma
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU).  Under torch.distributed.run (RANK set) it must equal "
@@ -250,6 +319,9 @@ def main():
     ap.add_argument("--inputs", default="", help="path prefix of an input cache (<prefix>.r<rank>of<world>.npz): loaded when present, "
                     "written when not; profiled runs load what an earlier, unprofiled command generated")
     ap.add_argument("--inputs-only", action="store_true", help="generate (and cache) the synthetic inputs, then exit: no GPU work")
+    ap.add_argument("--true-3d", action="store_true", help="with --config 5: the stack as a VOLUME (an extension beyond what the reference "
+                    "wires, SURVEY.md 8(d).5): every Z plane segmented, planes stitched along Z (IoU >= 0.01), 3-D intensity features; "
+                    "a tile is one [C,Z,Y,X] stack.  Without it config 5 is the reference-faithful projected form")
     ap.add_argument("--host-procs", type=int, default=0, help="host processes for input generation / the CPU baseline (default: all)")
     args = ap.parse_args()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -262,6 +334,10 @@ def main():
         return rehearse(args)
     if args.config == 4:
         return main_timelapse(args)
+    if args.true_3d:
+        if args.config != 5:
+            sys.exit("bench.py: --true-3d goes with --config 5")
+        return main_volume(args)
     cfg = CONFIGS[args.config]
     size = args.size or cfg["size"]
 
@@ -445,62 +521,7 @@ def main():
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - t0)
 
-    roof = roof_deep = None
-    fracs = {}
-    if prof:  # (--no-kernel-timing: nothing was bracketed)
-        # ---- roofline of the dominant hand-written kernel group ----------------------------------------------
-        hip_groups = {k: v for k, v in prof.items() if k not in ("unet_forward", "rows_d2h")}
-        dominant = max(hip_groups, key=lambda k: hip_groups[k]["ms_total"])
-        launches = hip_groups[dominant]["launches"]
-        avg_ms = hip_groups[dominant]["ms_total"] / launches
-        ab = alg_bytes(dominant, B, C, Z, Y, X, table.n_obj, n_tiles_net)
-        timed_launches = hip_groups[dominant].get("timed_launches", launches)
-        if dominant == "fused_pointwise":  # exact: operands read once + results written once, summed over the timed launches
-            ab = model.fused.bytes_moved / timed_launches
-        if dominant.startswith("conv3x3_mfma"):  # exact: input + residual read once, output (+ pooled) written once, per timed launch
-            ab = model.fused.conv_stats[dominant][0] / timed_launches
-        achieved = ab / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-        # FETCH_SIZE doubled on gfx950): measured offline, committed under profiles/, see profiles/pmc_traffic.json
-        traffic = None
-        pmc_file = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc_file.exists():
-            traffic = json.loads(pmc_file.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
-                "avg_launch_ms": round(avg_ms, 4), "launches": launches}
-        if dominant.startswith("conv3x3_mfma"):  # HBM-bound by design (144-288 FLOP/B); the matrix-core rate it sustains meanwhile
-            roof["mfma_tflops"] = round(model.fused.conv_stats[dominant][1] / timed_launches / (avg_ms * 1e-3) / 1e12, 1)
-        roof["timed_launches"] = timed_launches
-        # the deep levels' launches of the same kernel (128+ output channels): bound by the matrix cores
-        if "conv3x3_mfma_deep" in prof and prof["conv3x3_mfma_deep"].get("timed_launches"):
-            g = prof["conv3x3_mfma_deep"]
-            st = model.fused.conv_stats["conv3x3_mfma_deep"]
-            t_ms = g["ms_total"] / g["launches"]
-            tf = st[1] / g["timed_launches"] / (t_ms * 1e-3) / 1e12
-            roof_deep = {"bound": "mfma", "kernel": "conv3x3_mfma_deep", "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(tf / 2500.0, 4), "avg_launch_ms": round(t_ms, 4), "launches": g["launches"],
-                         "timed_launches": g["timed_launches"],
-                         "alg_gbps": round(st[0] / g["timed_launches"] / (t_ms * 1e-3) / 1e9, 1)}
-        # every HBM-bound group's fraction of the 8 TB/s peak: algorithmic bytes per launch / average launch time
-        for name, g in hip_groups.items():
-            if name.startswith("conv") or name in ("first_conv", "style", "out_head", "fused_pointwise"):
-                st = model.fused.conv_stats.get(name) if model.fused is not None else None
-                if not st or not g.get("timed_launches"):
-                    continue
-                gb = st[0] / g["timed_launches"]
-            else:
-                gb = alg_bytes(name, B, C, Z, Y, X, table.n_obj, n_tiles_net)
-            ms = g["ms_total"] / max(g["launches"], 1)
-            if ms > 0:
-                fracs[name] = round(gb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(steps, 1)
-    hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "conv3x3_mfma_head", "conv3x3_mfma_pair", "out_head",
-                                                                       "first_conv", "conv1x1_mfma", "style")) / max(steps, 1)
-    net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
-    mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,
-            "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3,
-            "path": "hand-written HIP (libaliby_hip.so)" if model.fused is not None else "torch module (MIOpen) - A/B reference, not the product path"}
+    roof, roof_deep, fracs, mfma = build_rooflines(prof, model, args, B, C, Z, Y, X, table.n_obj, n_tiles_net, steps)
 
     # ---- the same workload through the step API ------------------------------------------------------------------
     api = None
@@ -647,6 +668,190 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
                 "columns": cols, "parquet_bytes_per_fov": int(parquet_bytes / max(n_pos, 1)), "main_thread": stats},
         "api_split_ms_per_fov": split,
     }
+
+
+def _make_volume_input(job):
+    """One synthetic stack for the true-3-D leg: config-5 pixels, ellipsoid ground truth per plane, analytic flows per plane."""
+    from aliby_amd import synth
+
+    fov, size, C, Z, n_target = job
+    f = synth.make_fov(5, fov, shape=(size, size), n_channels=C, n_z=Z, n_target=n_target)
+    gt = synth.ellipsoid_planes(f["nuclei"], Z, seed=fov)
+    dP = np.zeros((Z, 2, size, size), np.float32)
+    prob = np.empty((Z, size, size), np.float32)
+    for z in range(Z):
+        uniq = np.unique(gt[z])
+        uniq = uniq[uniq != 0]
+        fwd = np.zeros(int(gt[z].max()) + 1, gt.dtype)
+        fwd[uniq] = np.arange(1, len(uniq) + 1)  # each plane labelled on its own, as a per-plane segmenter sees it
+        dP[z], prob[z] = synth.analytic_flows(fwd[gt[z]])
+    return dict(pixels=f["pixels"], gt=gt, dP=dP, prob=prob)
+
+
+def main_volume(args):
+    """Config 5 as a volume (BASELINE.json configs[4]: "3D Cellpose + 3D intensity features"; SURVEY.md 8(d).5's second number, an
+    extension beyond reference behaviour, parity unpinned): per step B stacks [C=2, Z=32, 512, 512] resident in HBM go through
+    stage -> every plane through normalise / tiles / U-Net / dynamics -> planes stitched along Z (the reference's stitch_threshold
+    = 0.01) -> 3-D intensity statistics on both channels -> rows to the host.  A tile is one stack."""
+    import multiprocessing as mp
+    import warnings
+
+    from aliby_amd import hostinfo, parallel
+
+    cfg = CONFIGS[5]
+    rank, world, local_rank = parallel.rank_world()
+    size = args.size or cfg["size"]
+    C, Z = cfg["C"], cfg["Z"]
+    B = args.fovs if args.fovs != 64 else 8
+    distinct = max(1, min(args.distinct, B))
+    procs = args.host_procs or hostinfo.usable_cores()
+    jobs = [(rank + world * i, size, C, Z, cfg["n_target"]) for i in range(distinct)]
+    if procs > 1 and len(jobs) > 1 and not under_profiler():
+        pool = mp.get_context("fork").Pool(min(procs, len(jobs)))
+        try:
+            base = pool.map(_make_volume_input, jobs, chunksize=1)
+        finally:
+            pool.close()
+            pool.join()
+    else:
+        base = [_make_volume_input(j) for j in jobs]
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_volume(base[0])
+
+    import torch
+
+    from aliby_amd import _lib
+
+    backend = os.environ.get("ALIBY_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_rank)
+    parallel.init(backend if world > 1 else None)
+    dist = torch.distributed if world > 1 else None
+    from aliby_amd.extraction.engine import _ptr, _stream_ptr
+    from aliby_amd.segment.cellpose_hip import CellposeModel
+
+    Y = X = size
+    stacks = torch.empty((B, C, Z, Y, X), dtype=torch.uint16, device="cuda")
+    dP_d = torch.empty((B * Z, 2, Y, X), dtype=torch.float32, device="cuda")
+    prob_d = torch.empty((B * Z, Y, X), dtype=torch.float32, device="cuda")
+    for b in range(B):
+        k = b % distinct
+        stacks[b] = torch.from_numpy(base[k]["pixels"]).cuda()
+        dP_d[b * Z:(b + 1) * Z] = torch.from_numpy(base[k]["dP"]).cuda()
+        prob_d[b * Z:(b + 1) * Z] = torch.from_numpy(base[k]["prob"]).cuda()
+    tiles = torch.empty_like(stacks)
+    rect = np.array([[0, 0, Y, X]], np.int32)
+    flags = np.zeros(1, np.int32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = CellposeModel(net_dtype=args.net_dtype, seed=0, flows_override=lambda x: (dP_d, prob_d), run_network_with_override=True,
+                              batch_size=args.net_batch)
+    eng = model.eng
+    n_tiles_net = B * Z * model._geometry(Y, X)["ny"] * model._geometry(Y, X)["nx"]
+    state = {"parity": 0}
+
+    def step():
+        with eng.timed("stage_crop_pad"):
+            _lib.check(eng.lib.aliby_crop_pad_u16(eng.ctx.handle, _ptr(stacks), B * C, Z, Y, X, _ptr(rect), 1, Y, X, _ptr(tiles), _ptr(flags),
+                                                  _stream_ptr()))
+        px = tiles.view(B, C, Z, Y, X)
+        planes = px[:, cfg["seg_channel"]].reshape(B * Z, Y, X)
+        masks, _, _ = model.eval(planes, do_3D=False, stitch_threshold=0.0, normalize=dict(norm3D=False), z_axis=None)
+        with eng.timed("stitch_planes"):
+            volume, counts = eng.stitch_planes(masks.view(B, Z, Y, X), threshold=0.01)
+        rows = [eng.intensity3d(volume, px, c, counts) for c in range(C)]
+        pending = eng.to_host_async(tuple(rows), slot=state["parity"])
+        state["parity"] ^= 1
+        return pending, counts
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.profile = None
+    for _ in range(max(args.warmup, 1)):
+        step()[0].wait()
+    eng.profile = None if args.no_kernel_timing else {}
+    eng.profile_sample = {k: args.time_every for k in ("conv3x3_mfma", "conv3x3_mfma_deep", "fused_pointwise", "conv1x1_mfma")}
+    eng._sample_count = {}
+    if model.fused is not None:
+        model.fused.bytes_moved = 0
+        model.fused.conv_stats = {}
+    steps = max(args.steps, 1)
+    barrier()
+    t0 = time.perf_counter()
+    pending = None
+    for _ in range(steps):
+        nxt, counts = step()
+        if pending is not None:
+            pending.wait()
+        pending = nxt
+    rows = pending.wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if backend != "nccl":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = eng.collect_profile()
+    eng.profile = None
+    n_obj = int(np.sum(counts))
+    roof, roof_deep, fracs, mfma = build_rooflines(prof, model, args, B * Z, 1, 1, Y, X, n_obj, n_tiles_net, steps)
+    truth = [len(np.unique(b["gt"][b["gt"] > 0])) for b in base]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "FOV tiles/sec (whole node)", "value": round(world * B * steps / dt, 3), "unit": "tiles/s", "n_gpus": world, "ranks": world,
+            "backend": (dist.get_backend() if dist is not None else None), "steps": steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"u16 pixels, exact integer sums -> f64 features, f32 dynamics, {args.net_dtype} U-Net", "data": "synthetic",
+            "config": {"workload": f"C5 as a VOLUME (extension beyond reference behaviour, parity unpinned; SURVEY.md 8(d).5): {B} stacks/step/GPU of "
+                                   f"[{C} ch, Z={Z}, {Y}x{X}], every plane segmented ({B * Z} planes, {n_tiles_net} network tiles per step), planes "
+                                   "stitched along Z by IoU >= 0.01, 12 3-D intensity columns per object and channel; a tile is one stack",
+                       "segmentation": "U-Net forward with fixed-seed random weights (cost paid, output discarded) + dynamics on analytic flows of the "
+                                       "per-plane ground truth (ellipsoids)",
+                       "objects_last_step": n_obj, "objects_ground_truth": int(np.sum([truth[b % distinct] for b in range(B)])),
+                       "planes_per_s": round(world * B * Z * steps / dt, 1), "columns": int(sum(r.shape[1] for r in rows))},
+            "roofline": roof, "roofline_mfma": roof_deep, "cpu_baseline": cpu, "mfma": mfma,
+            "kernel_ms_per_step": {k: round(v["ms_total"] / steps, 3) for k, v in prof.items()}, "kernel_hbm_frac": fracs,
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_volume(sample):
+    """The true-3-D leg on one core: the CPU restatement's dynamics on a few planes (scaled to the stack), stitching and the 3-D
+    intensity block on the whole stack.  The network forward is not part of this CPU figure."""
+    from oracle import cellpose_restated as cr
+    from oracle import volume_restated as vr
+    from oracle.cpu_baseline import cpu_model
+
+    Z = sample["gt"].shape[0]
+    zs = [Z // 2 - 1, Z // 2, Z // 2 + 1]
+    t0 = time.perf_counter()
+    planes = {z: cr.finish_labels(cr.compute_masks(sample["dP"][z], sample["prob"][z])) for z in zs}
+    t_dyn = (time.perf_counter() - t0) / len(zs) * Z
+    per_plane = []
+    for z in range(Z):  # (stitching and features are timed on per-plane labels derived from the ground truth)
+        uniq = np.unique(sample["gt"][z])
+        uniq = uniq[uniq != 0]
+        fwd = np.zeros(int(sample["gt"][z].max()) + 1, np.int64)
+        fwd[uniq] = np.arange(1, len(uniq) + 1)
+        per_plane.append(fwd[sample["gt"][z]])
+    t0 = time.perf_counter()
+    vol, n = vr.stitch3d(np.stack(per_plane), 0.01)
+    for c in range(sample["pixels"].shape[0]):
+        vr.intensity3d(vol, sample["pixels"][c])
+    t_rest = time.perf_counter() - t0
+    del planes
+    return {"value": round(1.0 / (t_dyn + t_rest), 4), "unit": "tiles/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+            "os_cpu_count": os.cpu_count(),
+            "sample": f"oracle (CPU restatement) on one stack: NumPy dynamics on 3 of {Z} planes scaled to the stack ({t_dyn:.1f} s) + Z "
+                      f"stitching + 3-D intensity on 2 channels ({t_rest:.1f} s), {n} objects; the network forward is not part of this CPU figure"}
 
 
 def main_timelapse(args):

@@ -178,7 +178,8 @@ int aliby_nn_conv3x3_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void*
  * cur_tracked_dev[row] receives the tracked label of every current object (0 for labels absent from the frame):
  * the previous tracked label of the best IoU >= threshold partner that is also that partner's best, else
  * max_label + 1, + 2, ... in current label order; max_label_out_host[tile] the new running maximum.
- * threshold in [1/8, 1] (cellpose's default is 0.25). */
+ * threshold in [0.01, 1] (cellpose's default is 0.25; the reference's 3-D branch passes 0.01, dispatch.py:195); more than 16
+ * previous objects above the threshold under one current mask is an error. */
 int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const uint16_t* cur, int F, int Y, int X,
                        const aliby_object* cur_table_dev, const int32_t* cur_offsets_host,
                        const aliby_object* prev_table_dev, const int32_t* prev_offsets_host,
@@ -483,6 +484,19 @@ int aliby_trap_match_template(aliby_ctx* ctx, const double* padded, int PH, int 
                               int tw, double* out, int H, int W, double t_mean, double t_ssd, void* stream);
 int aliby_trap_maxfilter1d(aliby_ctx* ctx, const double* in, double* out, int H, int W, int axis, int radius,
                            void* stream);
+
+/* ---- round 3 extension: a Z-stack as a volume (BASELINE config 5, "true 3-D"; beyond what the reference wires) -------- */
+/* Labels through a per-object table: out[t, p] = lut[offsets[t] + in[t, p] - 1] (0 stays 0): writes the Z-stitched labels
+ * (aliby_track_stitch along Z, the reference's stitch_threshold = 0.01 of dispatch.py:193-198) back into the planes.  A
+ * label >= 65535 is ALIBY_ERR_OVERFLOW. */
+int aliby_labels_apply_lut(aliby_ctx* ctx, const uint16_t* labels_in, int T, int Y, int X, const int32_t* offsets_host,
+                           const int32_t* lut_dev, uint16_t* labels_out, void* stream);
+/* Per-object intensity statistics over labelled stacks: labels uint16 [F,Z,Y,X] (labels 1..n_f per stack), pixels uint16
+ * [F,C,Z,Y,X]; object (f, label) is row offsets_host[f] + label - 1.  12 columns at out[row * ld + col0 ..]: Volume,
+ * IntegratedIntensity, MeanIntensity, StdIntensity (population), MinIntensity, MaxIntensity, CenterMassIntensity_X/Y/Z,
+ * Center_X/Y/Z.  Exact integer sums: run-to-run deterministic. */
+int aliby_features_intensity3d(aliby_ctx* ctx, const uint16_t* labels, const uint16_t* pixels, int F, int C, int Z, int Y,
+                               int X, int channel, const int32_t* offsets_host, double* out, int ld, int col0, void* stream);
 
 /* ---- a17: the step API's files, encoded natively (host code, no GPU work) ------------------ */
 /* profiles/<name>.parquet — pyarrow.parquet.write_table(profiles, path, compression="zstd")
