@@ -289,7 +289,9 @@ extern "C" int aliby_features_granularity(aliby_ctx* ctx, const uint16_t* labels
   if (dtype == ALIBY_U16) hipLaunchKernelGGL((k_gran_means<u16, true>), dim3(og), dim3(64), 0, s, m);
   else hipLaunchKernelGGL((k_gran_means<float, true>), dim3(og), dim3(64), 0, s, m);
   // 4. the spectrum
-  const int max_sweeps = 2 * (g.sh + g.sw) + 64;  // a geodesic path cannot be longer than the image has pixels on a staircase
+  // Jacobi sweeps move a value one pixel per sweep along a geodesic path, which in a serpentine mask can be as long as half the
+  // image has pixels: that is the hard cap (reaching it without convergence is reported, never returned as a result).
+  const long long max_total = (long long)g.sh * g.sw / 2 + 64;
   for (int step = 1; step <= spectrum_length; ++step) {
     double* next = spare[0];
     hipLaunchKernelGGL((k_gran_morph<false>), dim3(grid_for(ns)), dim3(256), 0, s, ero, msk, F, g.sh, g.sw, 1, next);
@@ -311,7 +313,12 @@ extern "C" int aliby_features_granularity(aliby_ctx* ctx, const uint16_t* labels
       HIP_TRY(hipMemcpyAsync(&changed, flag, sizeof(int), hipMemcpyDeviceToHost, s));
       int rc2 = aliby_wait_stream(s);
       if (rc2 != ALIBY_OK) return rc2;
-      if (!changed || sweeps >= max_sweeps * 16) break;
+      if (!changed) break;
+      if (sweeps >= max_total) {
+        aliby_set_error("granularity: the reconstruction of spectrum step %d did not converge within %d sweeps on a %d x %d image", step,
+                        sweeps, g.sh, g.sw);
+        return ALIBY_ERR_TOO_LARGE;
+      }
     }
     KERNEL_CHECK();
     m.rec = cur;

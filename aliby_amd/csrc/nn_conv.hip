@@ -193,6 +193,61 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int irow, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The network's output head on the matrix cores (round 3).  y[o] = hbias[o] + sum_c hw[o, c] * act(OUT[c]), act = bf16(relu(
+// hscale[c] * bf16(OUT[c]) + hshift[c])), 32 channels -> O <= 4 maps.  Rounds 1-2 summed the 96 products per pixel on the vector
+// unit, which cost the last unit half as much again as its whole 3x3 convolution and made the fused pair lose to two launches;
+// as two k-steps of the 32x32x16 MFMA (A = the head's weights in rows 0..O-1, B = the activated pixel) it is 2 of 20 MFMAs.
+// A lane holds channels 16 hh .. 16 hh + 15 of its pixel; the B fragment of k-step kc wants channels 16 kc + 8 hh .. + 7, so
+// the two lanes of a pixel swap one octet each (one 16-byte exchange through lane ^ 32).  All three forms of the head —
+// k_out_head, the last unit's epilogue, the fused pair's consumers — go through this function: same bits.
+struct HeadW { bf16x8_t w[2]; };
+
+__device__ __forceinline__ HeadW head_weights(const float* hw, int hO, int lane) {  // hw [hO][32] float32 (rounded to bf16 here)
+  HeadW h;
+  const int m = lane & 31, hh = lane >> 5, o = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    unsigned r4[4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
+      const int c = 16 * kc + 8 * hh + 2 * j2;
+      r4[j2] = cv_pack2(o < hO ? hw[o * 32 + c] : 0.f, o < hO ? hw[o * 32 + c + 1] : 0.f);
+    }
+    h.w[kc] = __builtin_bit_cast(bf16x8_t, make_uint4(r4[0], r4[1], r4[2], r4[3]));
+  }
+  return h;
+}
+
+// lo / hi: this lane's 16 channels of the unit's output as bf16 (two octets); sc / sh [0..31]: the head's BatchNorm affine.
+// Returns the MFMA result: outputs 0..3 are registers 0..3 of the hh == 0 lanes.
+__device__ __forceinline__ f32x16_t head_apply(uint4 lo, uint4 hi, const float* sc, const float* sh, const HeadW& hw, int hh) {
+  f32x2_t s2[4], h2[4];
+  const float* sp = sc + 16 * hh;
+  const float* hp = sh + 16 * hh;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s2[k] = f32x2_t{sp[2 * k], sp[2 * k + 1]}; h2[k] = f32x2_t{hp[2 * k], hp[2 * k + 1]}; }
+  const uint4 alo = conv_act8(lo, s2, h2, 0xffffffffu);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s2[k] = f32x2_t{sp[8 + 2 * k], sp[8 + 2 * k + 1]}; h2[k] = f32x2_t{hp[8 + 2 * k], hp[8 + 2 * k + 1]}; }
+  const uint4 ahi = conv_act8(hi, s2, h2, 0xffffffffu);
+  const uint4 send = hh ? alo : ahi;
+  const uint4 recv = make_uint4(__shfl_xor(send.x, 32), __shfl_xor(send.y, 32), __shfl_xor(send.z, 32), __shfl_xor(send.w, 32));
+  const uint4 b0 = hh ? recv : alo, b1 = hh ? ahi : recv;
+  f32x16_t y;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) y[k] = 0.f;
+  y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw.w[0], __builtin_bit_cast(bf16x8_t, b0), y, 0, 0, 0);
+  y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw.w[1], __builtin_bit_cast(bf16x8_t, b1), y, 0, 0, 0);
+  return y;
+}
+
+__device__ __forceinline__ f32x16_t head_from_acc(const f32x16_t& acc, const float* sc, const float* sh, const HeadW& hw, int hh) {
+  const uint4 lo = make_uint4(cv_pack2(acc[0], acc[1]), cv_pack2(acc[2], acc[3]), cv_pack2(acc[4], acc[5]), cv_pack2(acc[6], acc[7]));
+  const uint4 hi = make_uint4(cv_pack2(acc[8], acc[9]), cv_pack2(acc[10], acc[11]), cv_pack2(acc[12], acc[13]), cv_pack2(acc[14], acc[15]));
+  return head_apply(lo, hi, sc, sh, hw, hh);
+}
+
 template <int CIN, int COUT, bool TALL = false, bool PACK = false, bool HEAD = false>
 struct ConvCfg {
   static constexpr int KC = CIN / 16;    // MFMA k-steps per tap
@@ -266,14 +321,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     for (int i = 0; i < PK; ++i) pfrag[i] = pp[i * 64];
   }
   uint4* const ldsP = lds + NPL * PLANE;
-  __shared__ float hconst[HEAD ? 5 * 32 + 4 : 1];  // head: scale, shift, three weight rows, bias
+  __shared__ float hconst[HEAD ? 2 * 32 + 4 : 1];  // head: scale, shift, bias (the weights are MFMA fragments in registers)
+  HeadW hwf;
   if constexpr (HEAD) {
+    hwf = head_weights(a.hw, a.hO, lane);
     if (tid < 32) {
       hconst[tid] = a.hscale[tid];
       hconst[32 + tid] = a.hshift[tid];
-#pragma unroll
-      for (int o = 0; o < 3; ++o) hconst[64 + 32 * o + tid] = o < a.hO ? a.hw[o * 32 + tid] : 0.f;
-      if (tid < 4) hconst[160 + tid] = tid < a.hO ? a.hbias[tid] : 0.f;
+      if (tid < 4) hconst[64 + tid] = tid < a.hO ? a.hbias[tid] : 0.f;
     }
     // (visible to every wave after the first tile's barriers)
   }
@@ -428,37 +483,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       }
       if (pass == PASSES - 1) CONV_STAMP(5);
       if constexpr (HEAD) {
-        float tot[R][3];
-        __builtin_amdgcn_sched_barrier(0);  // the constants are loaded here, not above the MFMA loop (they would spill the weights)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float hs[8], hb[8], w0[8], w1[8], w2[8];
-          const float* hc = hconst + c0 + 8 * half;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) { hs[k] = hc[k]; hb[k] = hc[32 + k]; w0[k] = hc[64 + k]; w1[k] = hc[96 + k]; w2[k] = hc[128 + k]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float xb = cv_bf2f(cv_f2bf(acc[r][8 * half + k]));  // the value OUT holds
-              const float av = cv_bf2f(cv_f2bf(fmaxf(xb * hs[k] + hb[k], 0.0f)));
-              s0 += av * w0[k]; s1 += av * w1[k]; s2 += av * w2[k];
-            }
-            if (half == 0) { tot[r][0] = s0; tot[r][1] = s1; tot[r][2] = s2; }
-            else { tot[r][0] += s0; tot[r][1] += s1; tot[r][2] += s2; }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+        __builtin_amdgcn_sched_barrier(0);  // (nothing of the head is hoisted into the MFMA loop: it would spill the weights)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-#pragma unroll
-          for (int o = 0; o < 3; ++o) tot[r][o] += __shfl_xor(tot[r][o], 32);
+          const f32x16_t y = head_from_acc(acc[r], hconst, hconst + 32, hwf, hh);
           const int gy = y0 + rbase + r;
           if (hh == 0 && gx < a.W && gy < a.H) {
             float* hp = a.hout + (size_t)n * a.hO * a.H * a.W + (size_t)gy * a.W + gx;
-            for (int o = 0; o < a.hO; ++o) hp[(size_t)o * a.H * a.W] = tot[r][o] + hconst[160 + o];
+            const float yo[4] = {y[0], y[1], y[2], y[3]};
+            for (int o = 0; o < a.hO; ++o) hp[(size_t)o * a.H * a.W] = yo[o] + hconst[64 + o];
           }
         }
       }
@@ -726,7 +759,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_pair32(ConvArgs a) {
   uint4* const ldsIn = lds;
   uint4* const ldsMid0 = lds + NPL * PLANE_IN;
   __shared__ __align__(16) float tabB[64];  // unit B's scale[32], shift[32] of the producers' current tile
-  __shared__ float hconst[HEAD ? 5 * 32 + 4 : 1];  // output head: scale, shift, three weight rows, bias (see k_conv3x3)
+  __shared__ float hconst[HEAD ? 2 * 32 + 4 : 1];  // output head: scale, shift, bias (see k_conv3x3)
 
   const int consumer = threadIdx.x >> 8;            // wave-uniform: waves 4-7
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;  // role-local thread / wave index
@@ -846,13 +879,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_pair32(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 9 * KC; ++i) wB[i] = pb[i * 64];
     }
+    HeadW hwf;
     if constexpr (HEAD) {
+      hwf = head_weights(a.hw, a.hO, lane);
       if (tid < 32) {
         hconst[tid] = a.hscale[tid];
         hconst[32 + tid] = a.hshift[tid];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) hconst[64 + 32 * o + tid] = o < a.hO ? a.hw[o * 32 + tid] : 0.f;
-        if (tid < 4) hconst[160 + tid] = tid < a.hO ? a.hbias[tid] : 0.f;
+        if (tid < 4) hconst[64 + tid] = tid < a.hO ? a.hbias[tid] : 0.f;
       }  // (visible to the consumers after the two fill barriers below)
     }
     float4 b4[4] = {};
@@ -863,6 +896,8 @@ __global__ __launch_bounds__(512, 1) void k_conv_pair32(ConvArgs a) {
     }
     __syncthreads();  // the producers' first tile: its S1 ...
     __syncthreads();  // ... and S2
+    // (measured and NOT adopted, round 3: requesting a pass's residual rows one pass ahead instead of right before they seed the
+    // accumulators — 8.03 against 7.75 ms per step for the down-block pair: the consumers are not what the launch waits for)
     for (int it = 0; it < my_tiles; ++it) {
       const int tile = t_begin + it * nslots;
       const int tx = tile % a.tiles_x, tyn = tile / a.tiles_x;
@@ -880,35 +915,15 @@ __global__ __launch_bounds__(512, 1) void k_conv_pair32(ConvArgs a) {
           conv_seed<R>(acc, b4, rr, a.res != nullptr);
           __builtin_amdgcn_sched_barrier(0);
           conv_mfma<R, KC, cfg::DEPTH, PLANE_MID, MW>(reinterpret_cast<const bf16x8_t*>(ldsMid) + hh * PLANE_MID + rbase * MW + px, wB, acc);
-          if constexpr (HEAD) {  // the output head from the accumulators, in k_out_head's summation order (see k_conv3x3)
-            float tot[R][3];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              float hs[8], hb[8], w0[8], w1[8], w2[8];
-              const float* hc = hconst + c0 + 8 * half;
-#pragma unroll
-              for (int k = 0; k < 8; ++k) { hs[k] = hc[k]; hb[k] = hc[32 + k]; w0[k] = hc[64 + k]; w1[k] = hc[96 + k]; w2[k] = hc[128 + k]; }
-#pragma unroll
-              for (int r = 0; r < R; ++r) {
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                  const float xb = cv_bf2f(cv_f2bf(acc[r][8 * half + k]));
-                  const float av = cv_bf2f(cv_f2bf(fmaxf(xb * hs[k] + hb[k], 0.0f)));
-                  s0 += av * w0[k]; s1 += av * w1[k]; s2 += av * w2[k];
-                }
-                if (half == 0) { tot[r][0] = s0; tot[r][1] = s1; tot[r][2] = s2; }
-                else { tot[r][0] += s0; tot[r][1] += s1; tot[r][2] += s2; }
-              }
-            }
+          if constexpr (HEAD) {  // the output head from the accumulators (head_apply: the same bits as k_out_head)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-#pragma unroll
-              for (int o = 0; o < 3; ++o) tot[r][o] += __shfl_xor(tot[r][o], 32);
+              const f32x16_t y = head_from_acc(acc[r], hconst, hconst + 32, hwf, hh);
               const int gy = y0 + rbase + r;
               if (hh == 0 && gx < a.W && gy < a.H) {
                 float* hp = a.hout + (size_t)n * a.hO * a.H * a.W + (size_t)gy * a.W + gx;
-                for (int o = 0; o < a.hO; ++o) hp[(size_t)o * a.H * a.W] = tot[r][o] + hconst[160 + o];
+                const float yo[4] = {y[0], y[1], y[2], y[3]};
+                for (int o = 0; o < a.hO; ++o) hp[(size_t)o * a.H * a.W] = yo[o] + hconst[64 + o];
               }
             }
           }
@@ -1155,6 +1170,36 @@ __global__ __launch_bounds__(512, 1) void k_conv_first_pair(ConvArgs a) {
         }
         __syncthreads();  // pass 0: the producers' S1 of tile it + 1 (or their drain); pass 1: S2
       }
+    }
+  }
+}
+
+// The output head as its own launch (the form the fused variants are checked against, and the fallback when the last unit is
+// not the 32 -> 32 shape): x bf16 NHWC [P, 32] -> float32 [N, O, H*W].  One lane pair per pixel, 32 pixels per wave step.
+__global__ __launch_bounds__(256) void k_out_head_mfma(const uint4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ w, const float* __restrict__ bias, int O, size_t N, size_t P,
+                                                       float* __restrict__ out) {
+  __shared__ float hconst[2 * 32 + 4];
+  const int tid = threadIdx.x, lane = tid & 63, px = lane & 31, hh = lane >> 5;
+  if (tid < 32) {
+    hconst[tid] = scale[tid];
+    hconst[32 + tid] = shift[tid];
+    if (tid < 4) hconst[64 + tid] = tid < O ? bias[tid] : 0.f;
+  }
+  const HeadW hwf = head_weights(w, O, lane);
+  __syncthreads();
+  const size_t total = N * P, nblk = (total + 31) / 32;
+  const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + tid) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t b = wave0; b < nblk; b += nwaves) {
+    const size_t pix = b * 32 + px;
+    const bool ok = pix < total;
+    const size_t q = ok ? pix : total - 1;
+    const uint4 lo = x[q * 4 + 2 * hh], hi = x[q * 4 + 2 * hh + 1];
+    const f32x16_t y = head_apply(lo, hi, hconst, hconst + 32, hwf, hh);
+    if (ok && hh == 0) {
+      const size_t n = pix / P, p = pix - n * P;
+      const float yo[4] = {y[0], y[1], y[2], y[3]};
+      for (int o = 0; o < O; ++o) out[(n * O + o) * P + p] = yo[o] + hconst[64 + o];
     }
   }
 }
@@ -1452,6 +1497,20 @@ extern "C" int aliby_nn_first_pair_bf16(aliby_ctx* ctx, const float* tiles, int 
   const int per_xcd = (a.ntiles + 7) / 8;
   const int nslots = per_xcd < 32 ? per_xcd : 32;  // one 8-wave workgroup per CU, 32 CUs per XCD
   hipLaunchKernelGGL(k_conv_first_pair, dim3(8 * nslots), dim3(512), FirstPairCfg::LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+extern "C" int aliby_nn_out_head_bf16(aliby_ctx* ctx, const void* x, const float* scale, const float* shift, const float* w,
+                                      const float* bias, int N, int H, int W, int C, int O, float* out, void* stream) {
+  ARG_CHECK(ctx && x && scale && shift && w && bias && out, "out_head: null argument");
+  ARG_CHECK(C == 32 && O >= 1 && O <= 4, "out_head: C must be 32 and 1 <= O <= 4");
+  ARG_CHECK(N > 0 && H > 0 && W > 0, "out_head: empty shape");
+  const size_t P = (size_t)H * W, total = (size_t)N * P;
+  const size_t waves = (total + 31) / 32;
+  const unsigned blocks = (unsigned)((waves + 3) / 4 < 4096 ? (waves + 3) / 4 : 4096);
+  hipLaunchKernelGGL(k_out_head_mfma, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint4*>(x), scale, shift, w,
+                     bias, O, (size_t)N, P, out);
   KERNEL_CHECK();
   return ALIBY_OK;
 }

@@ -130,42 +130,7 @@ __global__ void k_nhwc_to_nchw_f32(const bf16_t* __restrict__ y, int N, int H, i
   }
 }
 
-// output head: y[n, o, p] = bias[o] + sum_c w[o, c] * bf16(relu(scale[c] * x[n, p, c] + shift[c])),  C = 32, O <= 4.
-// Four lanes share a pixel (one channel octet each, 16-byte loads) and combine through two DPP-class shuffles;
-// replaces a pointwise pass + a 1x1 convolution + a layout pass (3 launches, 2 intermediate tensors).
-__global__ __launch_bounds__(256) void k_out_head(const bf16_t* __restrict__ x, const float* __restrict__ scale,
-                                                  const float* __restrict__ shift, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, int O, size_t N, size_t P,
-                                                  float* __restrict__ out) {
-  const int c8 = threadIdx.x & 3;
-  float sc[8], sh[8], wq[4][8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 * 8 + k]; sh[k] = shift[c8 * 8 + k]; }
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wq[o][k] = o < O ? w[o * 32 + c8 * 8 + k] : 0.0f;
-  const size_t total = N * P * 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float a = bf2f(f2bf(fmaxf(bf2f(v.v[k]) * sc[k] + sh[k], 0.0f)));
-#pragma unroll
-      for (int o = 0; o < 4; ++o) acc[o] += a * wq[o][k];
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      acc[o] += __shfl_xor(acc[o], 1);
-      acc[o] += __shfl_xor(acc[o], 2);
-    }
-    if (c8 == 0) {
-      const size_t pix = i >> 2, n = pix / P, p = pix - n * P;
-      for (int o = 0; o < O; ++o) out[(n * O + o) * P + p] = acc[o] + bias[o];
-    }
-  }
-}
+// (the output head lives in nn_conv.hip since round 3: k_out_head_mfma, on the matrix cores)
 
 // style vector of the network and everything derived from it, one workgroup per sample:
 //   style[n, c]  = mean over (y, x) of X[n, y, x, c]            (cellpose `make_style`: global average pool ...
@@ -272,19 +237,6 @@ int aliby_nn_nhwc_to_nchw_f32(aliby_ctx* ctx, const void* y, int N, int H, int W
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(k_nhwc_to_nchw_f32, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)y, N, H, W, Cpad,
                      Cout, bias, out);
-  KERNEL_CHECK();
-  return ALIBY_OK;
-}
-
-int aliby_nn_out_head_bf16(aliby_ctx* ctx, const void* x, const float* scale, const float* shift, const float* w,
-                           const float* bias, int N, int H, int W, int C, int O, float* out, void* stream) {
-  ARG_CHECK(ctx && x && scale && shift && w && bias && out, "out_head: null argument");
-  ARG_CHECK(C == 32 && O >= 1 && O <= 4, "out_head: C must be 32 and 1 <= O <= 4");
-  ARG_CHECK(N > 0 && H > 0 && W > 0, "out_head: empty shape");
-  const size_t P = (size_t)H * W, total = (size_t)N * P * 4;  // total is a multiple of 4: a pixel never straddles a wave
-  const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
-  hipLaunchKernelGGL(k_out_head, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const bf16_t*>(x), scale, shift, w, bias, O, (size_t)N, P, out);
   KERNEL_CHECK();
   return ALIBY_OK;
 }

@@ -83,6 +83,9 @@ class FusedUNet:
         self.mfma_levels = tuple(mfma_levels)
         self.fused_head = os.environ.get("ALIBY_NET_FUSED_HEAD", "1") != "0"
         self.fused_pair = os.environ.get("ALIBY_NET_FUSED_PAIR", "1") != "0"  # level 0: conv2 + conv3 of a block in one launch
+        # the last block (conv2 + conv3 + output head) as one launch: built and bit-identical, but no faster than its two launches
+        # (A/B/A/B 588.6 / 586.5 / 579.9 / 585.2 tiles/s), so off by default
+        self.pair_head = os.environ.get("ALIBY_NET_PAIR_HEAD", "0") != "0"
         self.fused_first = os.environ.get("ALIBY_NET_FUSED_FIRST", "1") != "0"  # the first layer + conv1 + projection in one launch
         # deep levels (128 / 256 channels): one K-loop launch per convolution (csrc/nn_conv_deep.hip); 0 = the K/N-slice launches
         self.deep_kernel = os.environ.get("ALIBY_CONV_DEEP", "1") != "0"
@@ -406,10 +409,12 @@ class FusedUNet:
         c0s = self._unit(x, u[0], bias=u[0].bias, res=skip, in_up=up)  # wider than one launch holds: split along K / N
         sh = [self._style_shift(k) for k in u[1:]]  # [N,C] views of the batched style projection
         x1 = self._unit(c0s, u[1], shift=sh[0], bias=d["pb1"], res=p_low, res_up=up)
-        # (with the output head in its consumers' epilogue the pair measures 1139 us against 454 + 610 for conv2 and the
-        # unit-with-head launch: the head's arithmetic lands on the four consumer waves only — so the last block keeps two launches)
-        if self.fused_pair and head_out is None and tuple(u[2].w32.shape[:2]) == (32, 32) and tuple(u[3].w32.shape[:2]) == (32, 32):
-            return self._pair(x1, u[2], u[3], sh[1], sh[2], u[2].bias, u[3].bias, x1)
+        # (round 2: with the head summed on the vector unit in its consumers' epilogue the pair measured 1139 us against 454 + 610 for
+        # conv2 and the unit-with-head launch; round 3: the head is two MFMA k-steps (csrc/nn_conv.hip, head_apply), the pair with
+        # the head measures 944 us against 412 + 512: a tie, so the two launches stay the default — ALIBY_NET_PAIR_HEAD=1 for the pair)
+        pair_shapes = tuple(u[2].w32.shape[:2]) == (32, 32) and tuple(u[3].w32.shape[:2]) == (32, 32)
+        if self.fused_pair and pair_shapes and (head_out is None or self.pair_head):
+            return self._pair(x1, u[2], u[3], sh[1], sh[2], u[2].bias, u[3].bias, x1, head_out=head_out)
         c2 = self._unit(x1, u[2], shift=sh[1], bias=u[2].bias)
         if head_out is not None:
             self._unit_head(c2, u[3], sh[2], u[3].bias, x1, head_out)

@@ -282,8 +282,9 @@ int aliby_nn_style_bf16(aliby_ctx* ctx, const void* x, int N, int H, int W, int 
                         float* style, float* shifts, void* stream);
 /* Output head of the network (cellpose CPnet.output = BatchNorm -> ReLU -> 1x1 Conv2d, the flows + cellprob
  * that `model.eval` (segment/dispatch.py:208-215) returns): x bf16 NHWC [N,H,W,32] -> float32 NCHW [N,O,H,W],
- * y = bias[o] + sum_c w[o,c] * bf16(relu(scale[c]*x + shift[c])); w is float32 [O,32] (bf16-representable values
- * reproduce the bf16 convolution it replaces). */
+ * y = bias[o] + sum_c bf16(w[o,c]) * bf16(relu(scale[c]*x + shift[c])); w is float32 [O,32], rounded to bf16 as the bf16
+ * convolution it replaces holds it.  Round 3: two k-steps of the 32x32x16 MFMA per 32 pixels (csrc/nn_conv.hip, head_apply)
+ * — the same function the fused forms (aliby_nn_conv3x3_head_bf16, aliby_nn_conv3x3_pair_bf16) call: same bits. */
 int aliby_nn_out_head_bf16(aliby_ctx* ctx, const void* x, const float* scale, const float* shift, const float* w,
                            const float* bias, int N, int H, int W, int C, int O, float* out, void* stream);
 /* float32 NCHW network tiles (Cin <= 8) -> bf16 NHWC padded to 8 channels: raw copy and relu(bn(x)). */

@@ -361,3 +361,24 @@ def test_network_with_fused_first_pair_matches_the_separate_launches(engine):
     model.fused.fused_first = False
     want = model.run_network(img)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_network_last_block_as_pair_with_head_matches_the_two_launches(engine):
+    """Round 3: the output head is two MFMA k-steps in all of its forms, and the last block (conv2 + conv3 + head) runs as the
+    wave-specialised pair (ALIBY_NET_PAIR_HEAD=1; a tie in time, so not the default); the forward gives exactly the bits of the conv2 launch followed by the unit-with-head launch."""
+    import warnings
+
+    import torch
+    from aliby_amd.segment.cellpose_hip import CellposeModel
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = CellposeModel(net_dtype="bfloat16", seed=6, batch_size=4)
+    f = synth.make_fov(1, 11, shape=(300, 420), n_target=12)
+    img = torch.from_numpy(f["pixels"][0, 0][None]).cuda()
+    assert model.fused is not None and model.fused.fused_pair
+    model.fused.pair_head = True
+    got = model.run_network(img)
+    model.fused.pair_head = False
+    want = model.run_network(img)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
