@@ -407,6 +407,7 @@ int aliby_parquet_write(const char* path, const aliby_pq_column* cols, int n_col
 
 int aliby_npz_write(const char* path, const aliby_npy_member* members, int n_members, int level) {
   ARG_CHECK(path && members && n_members > 0, "npz_write: null argument");
+  ARG_CHECK(n_members <= 65535, "npz_write: more than 65535 members need zip64 (not written here)");
   ARG_CHECK(level >= 0 && level <= 9, "npz_write: deflate level 0..9");
   try {
     File out(path);
