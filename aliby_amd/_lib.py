@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libaliby_hip.so"
+LIB_PATH = Path(os.environ["ALIBY_HIP_LIB"]) if os.environ.get("ALIBY_HIP_LIB") else _HERE / "libaliby_hip.so"  # (the override: diagnostic builds)
 
 OK, ERR_INVALID, ERR_OVERFLOW, ERR_HIP, ERR_TOO_LARGE, ERR_UNSUPPORTED = range(6)
 U16, F32 = 0, 1

@@ -24,6 +24,12 @@
 //     through a 3-deep ring, seven MFMAs of cover each;
 //   * two workgroups per CU (<= 256 VGPRs, 44 KiB of LDS each) overlap each other's staging and MFMA phases.
 #include "common.h"
+#ifndef DC_REQ_AT
+#define DC_REQ_AT 27  // weight fragment (of 36 per slice) before which the next slice's window is requested
+#endif
+#ifndef DC_HACK
+#define DC_HACK 0  // diagnostics (scripts/deep_phases.sh): compile-time phase switches, timing only, results wrong
+#endif
 #include <stdlib.h>
 #include <utility>
 
@@ -96,8 +102,14 @@ constexpr int DC_PLANE = DC_WIN_MAX | 1;       // odd slot pitch: the 8 octets o
 constexpr int DC_ITERS = (DC_WIN_MAX + 31) / 32;  // staging rounds: 32 positions x 8 octets per round of 256 threads
 // planes + per-thread input offsets + prologue constants + per-thread output / residual offsets
 constexpr int DC_LDS_BYTES = 8 * DC_PLANE * 16 + DC_ITERS * 256 * 4 + 3 * 256 * 4 + 2 * DC_NB * 256 * 4;
-constexpr int DC_WDEPTH = 3;          // weight fragments in flight
-constexpr int DC_PDEPTH = 4;          // pixel fragments in flight
+#ifndef DC_WDEPTH_
+#define DC_WDEPTH_ 3
+#endif
+#ifndef DC_PDEPTH_
+#define DC_PDEPTH_ 4
+#endif
+constexpr int DC_WDEPTH = DC_WDEPTH_;  // weight fragments in flight
+constexpr int DC_PDEPTH = DC_PDEPTH_;  // pixel fragments in flight
 
 template <int CIN, bool UP>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
     auto request = [&](int s) {
       const uint4* inS = a.in + s * 8;
 #pragma unroll
-      for (int it = 0; it < DC_ITERS; ++it) v[it] = inS[(unsigned)goff[it * 256]];
+      for (int it = 0; it < DC_ITERS; ++it) { if constexpr (!(DC_HACK & 32)) v[it] = inS[(unsigned)goff[it * 256]]; else v[it] = make_uint4(it, 1, 2, 3); }
     };
     request(0);
 
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
       float b16[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) b16[k] = a.bias ? a.bias[c0 + k] : 0.f;
-      if (a.res) {
+      if (a.res && !(DC_HACK & 64)) {
         const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
         uint4 rr[DC_NB][2];
         {
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
       const bf16x8_t* wp = wbase + (size_t)(4 * s) * 64;  // fragment (tap, kc) of this slice at wp[(tap * KCT + kc) * 64]
       constexpr int NW = 36;  // weight fragments per slice, in (kc, tap) order
       bf16x8_t wring[DC_WDEPTH];
-      auto wfrag = [&](int i) { return wp[((i % 9) * KCT + (i / 9)) * 64]; };
+      auto wfrag = [&](int i) { if constexpr (DC_HACK & 2) return wp[0]; else return wp[((i % 9) * KCT + (i / 9)) * 64]; };
 #pragma unroll
       for (int i = 0; i < DC_WDEPTH - 1; ++i) wring[i] = wfrag(i);
       // the slice's prologue constants for this thread's octet
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
         f32x2_t shs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) shs[k] = ((later >> it) & 1u) ? sh1[k] : sh[k];
-        const uint4 o = dc_act8(v[it], sc, shs, 0u - ((inside >> it) & 1u));
+        const uint4 o = (DC_HACK & 8) ? v[it] : dc_act8(v[it], sc, shs, 0u - ((inside >> it) & 1u));
         const int wp_ = pos0 + 32 * it;
         if (wp_ < WIN) lds[pl * DC_PLANE + wp_] = o;
       }
@@ -251,13 +263,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
       bf16x8_t pring[DC_PDEPTH];
       auto pfrag = [&](int f) {
         const int i = f / DC_NB, b = f % DC_NB, kc = i / 9, tap = i % 9;
-        return L[2 * kc * DC_PLANE + b * 32 + row_off[tap / 3] + tap % 3];
+        if constexpr (DC_HACK & 4) return L[f & 3]; else return L[2 * kc * DC_PLANE + b * 32 + row_off[tap / 3] + tap % 3];
       };
 #pragma unroll
       for (int f = 0; f < DC_PDEPTH - 1; ++f) pring[f] = pfrag(f);
       sfor<NW>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (i == 27) {  // the last k-step starts: request the next slice's window
+        if constexpr (i == DC_REQ_AT) {  // request the next slice's window (see DC_REQ_AT)
           if (s + 1 < S) request(s + 1);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -269,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[(f & ~1) % DC_PDEPTH], acc[b], 0, 0, 0);
 #else
           if constexpr (f + DC_PDEPTH - 1 < NF) pring[(f + DC_PDEPTH - 1) % DC_PDEPTH] = pfrag(f + DC_PDEPTH - 1);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], acc[b], 0, 0, 0);
+          if constexpr (!(DC_HACK & 1)) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], acc[b], 0, 0, 0);
+          else { acc[b][0] += (float)(__builtin_bit_cast(uint4, wring[i % DC_WDEPTH]).x + __builtin_bit_cast(uint4, pring[f % DC_PDEPTH]).x); }
 #endif
         });
         __builtin_amdgcn_sched_barrier(0);
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
       for (int b = 0; b < DC_NB; ++b) {
         const int x = c - 1;
         const bool ok = q0 + b * 32 + px < a.q_end && y < a.H && x >= 0 && x < a.W && n < a.N;
-        if (ok) {
+        if (ok && (!(DC_HACK & 16) || acc[b][3] == 12345.f)) {
           uint4* op = a.out + (unsigned)(((n * a.H + y) * a.W + x) * ocs + (c0 >> 3));
           op[0] = make_uint4(dc_pack2(acc[b][0], acc[b][1]), dc_pack2(acc[b][2], acc[b][3]), dc_pack2(acc[b][4], acc[b][5]),
                              dc_pack2(acc[b][6], acc[b][7]));
@@ -317,6 +330,251 @@ int launch_deep(DeepArgs& a, hipStream_t stream) {
   static const int cap = [] { const char* e = getenv("ALIBY_DEEP_SLOTS"); return e ? atoi(e) : 64; }();  // 2 workgroups per CU, 32 CUs per XCD
   const int nslots = per_xcd < cap ? per_xcd : cap;
   hipLaunchKernelGGL((k_conv3x3_deep<CIN, UP>), dim3(8 * nslots), dim3(256), DC_LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loader-specialised form of the same unit (round 3).  Phase elimination on k_conv3x3_deep (scripts/deep_phases.sh, timing only):
+// without the window loads 256 -> 256 runs 24 % faster, without residual loads 9 %, without stores 9 %, without all three
+// 31 % (1458 TFLOP/s) — although the loads are issued a k-step ahead, and moving the request anywhere in the slice changes
+// nothing.  The reason is the in-order vmcnt counter: a wave's weight-fragment waits (L2 hits, a few hundred cycles) cannot pass
+// the HBM window loads the same wave issued before them, so every slice stalls for one loaded HBM latency in the middle of its
+// MFMA stream.  Here the two kinds of traffic sit in different waves:
+//   waves 0-3 (MFMA): stream weight fragments and issue MFMAs, nothing else inside a slice (residual loads and stores once per tile);
+//   waves 4-5 (loaders): bring the next slice's window in by LDS-DMA (each wave owns its units of the raw image: no loader-to-loader
+//     hand-off), run it through the prologue into the OTHER of two plane images, request the slice after that, and meet the MFMA
+//     waves at ONE workgroup barrier per slice.
+// One workgroup (4 MFMA + DL_NLW loader waves, ~132 KB of LDS) per CU.  Same MFMA order as k_conv3x3_deep: same bits.
+#ifndef DL_HACK
+#define DL_HACK 0  // diagnostics like DC_HACK: 1 loaders idle, 2 no MFMA loop, 4 no residual, 8 no stores, 16 no prologue math, 32 no DMA
+#endif
+#ifndef DL_NLW
+#define DL_NLW 4                                          // loader waves
+#endif
+constexpr int DL_LT = DL_NLW * 64;                        // loader threads
+constexpr int DL_UNITS = DC_WIN_MAX * 8;                  // 16-byte units of a slice's window (position-major, 8 octets each)
+constexpr int DL_ROUNDS = (DL_UNITS + DL_LT - 1) / DL_LT; // DMA instructions per loader wave and slice
+constexpr int DL_LDS_BYTES = 2 * 8 * DC_PLANE * 16 + DL_ROUNDS * DL_LT * 16;
+
+template <int CIN, bool UP>
+__global__ __launch_bounds__(256 + DL_LT, 1) void k_conv3x3_deep_ls(DeepArgs a) {
+  constexpr int S = CIN / 64, KCT = CIN / 16;
+  extern __shared__ uint4 lds[];
+  uint4* const planes0 = lds;
+  uint4* const rawbuf = lds + 2 * 8 * DC_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int IH = UP ? a.H >> 1 : a.H, IW = UP ? a.W >> 1 : a.W;
+  const int LW = a.LW, HP = a.HP;
+  const int WIN = DC_RUN + 2 * LW + 2;
+  const int cs = CIN / 8;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd + slot, t_end = min(a.ntiles, (xcd + 1) * per_xcd);
+  const int my_tiles = t_begin < t_end ? (t_end - t_begin + nslots - 1) / nslots : 0;
+  const int G = my_tiles * S;  // slices this workgroup goes through: one barrier each, for every wave
+
+  if (wave >= 4) {
+    // =========================================================================================== loaders
+    const int lt = tid - 256;                 // 0..DL_LT-1
+    const int oct = lt & 7;                   // this lane's channel octet of the slice (units lt + DL_LT k: positions (lt >> 3) + DL_LT/8 k)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave - 4);
+    int goff[DL_ROUNDS];                      // input offsets (16-byte units) of this lane's units, slice 0
+    unsigned inside = 0, later = 0;
+    int n0 = 0, n1 = 0;
+    auto tile_offsets = [&](int tile) {
+      const int run = tile / a.nhalf;
+      const int q0 = a.q_begin + run * DC_RUN;
+      const int p_first = q0 - LW - 1;
+      n0 = max(0, ((p_first / LW) - 1) / HP);
+      n1 = min(n0 + 1, a.N - 1);
+      inside = 0;
+      later = 0;
+#pragma unroll
+      for (int k = 0; k < DL_ROUNDS; ++k) {
+        const int wp_ = (lt >> 3) + (DL_LT / 8) * k;    // window position of unit lt + DL_LT k
+        const int P0 = p_first + wp_;         // >= -1
+        const int r = P0 >= 0 ? P0 / LW : -1, c = P0 - r * LW;
+        const int n = r >= 1 ? (r - 1) / HP : 0, y = r >= 1 ? (r - 1) - n * HP : r - 1;
+        const bool ok = wp_ < WIN && y >= 0 && y < a.H && c >= 1 && c <= a.W && n < a.N;
+        inside |= (unsigned)ok << k;
+        later |= (unsigned)(n > n0) << k;
+        const int nn = min(n, a.N - 1), yy = min(max(y, 0), a.H - 1), xx = min(max(c - 1, 0), a.W - 1);
+        goff[k] = ((nn * IH + (UP ? yy >> 1 : yy)) * IW + (UP ? xx >> 1 : xx)) * cs + oct;
+      }
+    };
+    auto issue_dma = [&](int s) {  // this wave's units of slice s -> rawbuf (lane-linear: unit u lands at rawbuf[u])
+      const uint4* inS = a.in + s * 8;
+#pragma unroll
+      for (int k = 0; k < DL_ROUNDS; ++k)
+        if constexpr (!(DL_HACK & 32)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(inS + (unsigned)goff[k]),
+                                         (__attribute__((address_space(3))) void*)(rawbuf + k * DL_LT + wave_u * 64), 16, 0, 0);
+    };
+    auto activate = [&](int s, uint4* planes) {  // rawbuf -> prologue -> channel-octet planes
+      f32x2_t sc[4], sh[4], sh1[4];
+      const int ch = s * 64 + oct * 8;
+      const float* sp0 = a.shift + (size_t)n0 * a.shift_stride + ch;
+      const float* sp1 = a.shift + (size_t)n1 * a.shift_stride + ch;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sc[k] = f32x2_t{a.scale[ch + 2 * k], a.scale[ch + 2 * k + 1]};
+        sh[k] = f32x2_t{sp0[2 * k], sp0[2 * k + 1]};
+        sh1[k] = f32x2_t{sp1[2 * k], sp1[2 * k + 1]};
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (and the constants above) have landed
+#pragma unroll
+      for (int k = 0; k < DL_ROUNDS; ++k) {
+        const int wp_ = (lt >> 3) + (DL_LT / 8) * k;
+        if (wp_ >= WIN) break;
+        f32x2_t shs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) shs[q] = ((later >> k) & 1u) ? sh1[q] : sh[q];
+        if constexpr (DL_HACK & 16) planes[oct * DC_PLANE + wp_] = rawbuf[k * DL_LT + lt];
+        else planes[oct * DC_PLANE + wp_] = dc_act8(rawbuf[k * DL_LT + lt], sc, shs, 0u - ((inside >> k) & 1u));
+      }
+    };
+    // slice g of the workgroup = (tile g / S, slice g % S); prepared one barrier ahead of its MFMAs
+    if (G > 0) {
+      tile_offsets(t_begin);
+      issue_dma(0);
+      activate(0, planes0);
+      if (G > 1) {
+        if (S == 1) tile_offsets(t_begin + nslots);
+        issue_dma(1 % S);
+      }
+    }
+    for (int g = 0; g < G; ++g) {
+      __syncthreads();  // B_g: planes[g & 1] hold slice g; the MFMA waves are done with planes[(g + 1) & 1]
+      if (g + 1 < G && !(DL_HACK & 1)) {
+        const int s1 = (g + 1) % S;
+        activate(s1, planes0 + ((g + 1) & 1) * 8 * DC_PLANE);  // (its offsets / masks are the ones its DMA was issued with)
+        if (g + 2 < G) {
+          const int s2 = (g + 2) % S;
+          if (s2 == 0) tile_offsets(t_begin + ((g + 2) / S) * nslots);
+          issue_dma(s2);
+        }
+      }
+    }
+    return;
+  }
+
+  // ============================================================================================= MFMA waves
+  const int cb = wave, px = lane & 31, hh = lane >> 5;
+  const int ocs = a.COUT / 8;
+  const int row_off[3] = {0, LW, 2 * LW};
+  int g = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int tile = t_begin + ti * nslots;
+    const int half = tile % a.nhalf, run = tile / a.nhalf;
+    const int q0 = a.q_begin + run * DC_RUN;
+    const int c0 = half * 128 + cb * 32 + hh * 16;
+    f32x16_t acc[DC_NB];
+    {
+      float b16[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) b16[k] = a.bias ? a.bias[c0 + k] : 0.f;
+      if (a.res && !(DL_HACK & 4)) {
+        const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
+        uint4 rr[DC_NB][2];
+        {
+          const int q = q0 + px;
+          int r = q / LW, c = q - r * LW;
+          int n = (r - 1) / HP, y = (r - 1) - n * HP;
+#pragma unroll
+          for (int b = 0; b < DC_NB; ++b) {
+            const int nn = min(n, a.N - 1), yy = min(y, a.H - 1), xx = min(max(c - 1, 0), a.W - 1);
+            const unsigned roff = (unsigned)(((nn * RH + (yy >> a.res_up)) * RW + (xx >> a.res_up)) * ocs + (c0 >> 3));
+            rr[b][0] = a.res[roff];
+            rr[b][1] = a.res[roff + 1];
+            c += 32;
+            while (c >= LW) {
+              c -= LW;
+              if (++y == HP) { y = 0; ++n; }
+            }
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < DC_NB; ++b) {
+          const unsigned rw[8] = {rr[b][0].x, rr[b][0].y, rr[b][0].z, rr[b][0].w, rr[b][1].x, rr[b][1].y, rr[b][1].z, rr[b][1].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[b][2 * j] = b16[2 * j] + dc_bf2f(rw[j] & 0xffffu);
+            acc[b][2 * j + 1] = b16[2 * j + 1] + dc_bf2f(rw[j] >> 16);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < DC_NB; ++b)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[b][k] = b16[k];
+      }
+    }
+    const bf16x8_t* wbase = reinterpret_cast<const bf16x8_t*>(a.wpk) + (size_t)(half * 4 + cb) * 9 * KCT * 64 + lane;
+    for (int s = 0; s < S; ++s, ++g) {
+      const bf16x8_t* wp = wbase + (size_t)(4 * s) * 64;
+      constexpr int NW = 36;
+      bf16x8_t wring[DC_WDEPTH];
+      auto wfrag = [&](int i) { if constexpr (DL_HACK & 64) return wp[0]; else return wp[((i % 9) * KCT + (i / 9)) * 64]; };
+#pragma unroll
+      for (int i = 0; i < DC_WDEPTH - 1; ++i) wring[i] = wfrag(i);
+      __syncthreads();  // B_g
+      const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(planes0 + (g & 1) * 8 * DC_PLANE) + hh * DC_PLANE + px;
+      constexpr int NF = NW * DC_NB;
+      bf16x8_t pring[DC_PDEPTH];
+      auto pfrag = [&](int f) {
+        const int i = f / DC_NB, b = f % DC_NB, kc = i / 9, tap = i % 9;
+        if constexpr (DL_HACK & 128) return L[f & 3]; else return L[2 * kc * DC_PLANE + b * 32 + row_off[tap / 3] + tap % 3];
+      };
+#pragma unroll
+      for (int f = 0; f < DC_PDEPTH - 1; ++f) pring[f] = pfrag(f);
+      if constexpr (!(DL_HACK & 2)) sfor<NW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i + DC_WDEPTH - 1 < NW) wring[(i + DC_WDEPTH - 1) % DC_WDEPTH] = wfrag(i + DC_WDEPTH - 1);
+        sfor<DC_NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value, f = i * DC_NB + b;
+          if constexpr (f + DC_PDEPTH - 1 < NF) pring[(f + DC_PDEPTH - 1) % DC_PDEPTH] = pfrag(f + DC_PDEPTH - 1);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], acc[b], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int q = q0 + px;
+      int r = q / LW, c = q - r * LW;
+      int n = (r - 1) / HP, y = (r - 1) - n * HP;
+#pragma unroll
+      for (int b = 0; b < DC_NB; ++b) {
+        const int x = c - 1;
+        const bool ok = q0 + b * 32 + px < a.q_end && y < a.H && x >= 0 && x < a.W && n < a.N;
+        if (ok && (!(DL_HACK & 8) || acc[b][3] == 12345.f)) {
+          uint4* op = a.out + (unsigned)(((n * a.H + y) * a.W + x) * ocs + (c0 >> 3));
+          op[0] = make_uint4(dc_pack2(acc[b][0], acc[b][1]), dc_pack2(acc[b][2], acc[b][3]), dc_pack2(acc[b][4], acc[b][5]),
+                             dc_pack2(acc[b][6], acc[b][7]));
+          op[1] = make_uint4(dc_pack2(acc[b][8], acc[b][9]), dc_pack2(acc[b][10], acc[b][11]), dc_pack2(acc[b][12], acc[b][13]),
+                             dc_pack2(acc[b][14], acc[b][15]));
+        }
+        c += 32;
+        while (c >= LW) {
+          c -= LW;
+          if (++y == HP) { y = 0; ++n; }
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, bool UP>
+int launch_deep_ls(DeepArgs& a, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_deep_ls<CIN, UP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DL_LDS_BYTES));
+    attr_done = true;
+  }
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int nslots = per_xcd < 32 ? per_xcd : 32;  // one workgroup per CU, 32 CUs per XCD
+  hipLaunchKernelGGL((k_conv3x3_deep_ls<CIN, UP>), dim3(8 * nslots), dim3(256 + DL_LT), DL_LDS_BYTES, stream, a);
   KERNEL_CHECK();
   return ALIBY_OK;
 }
@@ -402,6 +660,12 @@ extern "C" int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const 
   static const int stagger = [] { const char* e = getenv("ALIBY_DEEP_STAGGER"); return e ? atoi(e) : 0; }();
   a.stagger = stagger;
   a.trace = g_deep_trace;
+  const char* ls = getenv("ALIBY_DEEP_LS");  // loader-specialised form: measured slower, kept for A/B; read per call
+  if (ls && atoi(ls)) {
+    if (CIN == 64) return in_up ? launch_deep_ls<64, true>(a, stream) : launch_deep_ls<64, false>(a, stream);
+    if (CIN == 128) return in_up ? launch_deep_ls<128, true>(a, stream) : launch_deep_ls<128, false>(a, stream);
+    return in_up ? launch_deep_ls<256, true>(a, stream) : launch_deep_ls<256, false>(a, stream);
+  }
   if (CIN == 64) return in_up ? launch_deep<64, true>(a, stream) : launch_deep<64, false>(a, stream);
   if (CIN == 128) return in_up ? launch_deep<128, true>(a, stream) : launch_deep<128, false>(a, stream);
   return in_up ? launch_deep<256, true>(a, stream) : launch_deep<256, false>(a, stream);

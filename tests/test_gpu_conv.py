@@ -454,6 +454,28 @@ def test_deep_conv_exact_on_integer_data(engine, cin, cout, in_up, shape):
     assert torch.equal(out2.float(), _reference(x, w, scale, shift[0], None, None, False, in_up))
 
 
+@pytest.mark.parametrize("cin,cout,in_up", DEEP)
+def test_deep_conv_loader_specialised_form_has_the_same_bits(engine, cin, cout, in_up, monkeypatch):
+    """ALIBY_DEEP_LS=1 selects k_conv3x3_deep_ls (MFMA waves + LDS-DMA loader waves, not the default: DESIGN.md 3.2): same MFMA
+    order, so the same bits as the default kernel on random data."""
+    import torch
+
+    g = torch.Generator().manual_seed(cin + cout)
+    n, H, W = 5, 56, 56
+    ih, iw = (H // 2, W // 2) if in_up else (H, W)
+    x = torch.randn(n, ih, iw, cin, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    scale = (torch.rand(cin, generator=g) + 0.5).cuda()
+    shift = torch.randn(n, cin, generator=g).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(n, H // 2, W // 2, cout, generator=g).to(torch.bfloat16).cuda()
+    monkeypatch.delenv("ALIBY_DEEP_LS", raising=False)
+    ref = _run_deep(engine, x, w, scale, shift, bias, res, True, in_up, H, W)
+    monkeypatch.setenv("ALIBY_DEEP_LS", "1")
+    out = _run_deep(engine, x, w, scale, shift, bias, res, True, in_up, H, W)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
 def test_deep_conv_random_data_is_closer_to_fp32_than_the_sliced_launches(engine):
     """Random data: the K-loop kernel rounds to bf16 once (|err| <= 2^-8 of the value + fp32 summation noise); the K-split
     launches it replaces rounded their partial sums to bf16 three times for a 256-channel input."""
