@@ -140,6 +140,7 @@ _SIGNATURES = {
     "aliby_parquet_write": (_i, [C.c_char_p, _vp, _i, _vp, _i, _vp, _vp, _i]),
     "aliby_npz_write": (_i, [C.c_char_p, _vp, _i, _i]),
     "aliby_host_codecs": (_i, [C.POINTER(_i), C.POINTER(_i)]),
+    "aliby_host_copy": (_i, [_vp, _vp, _sz, _i]),
     "aliby_object_ranks": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
 }
 

@@ -18,12 +18,17 @@
 // interpreter lock released, so files of different positions are encoded side by side without writer processes.
 #include "common.h"
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
 #include <atomic>
 #include <mutex>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -113,11 +118,34 @@ struct Deflate {
 };
 const Deflate& deflater() { static Deflate d; return d; }
 
+// A file is assembled in memory (a buffer the thread keeps from file to file) and handed to the kernel in ONE write: through
+// stdio's 4 KiB buffer a 2 MB profiles file is ~500 write calls, and on a journalled file system a dozen writer threads doing
+// that side by side ran at 2.5x the thread-time per file of the same code on tmpfs.
 struct File {
-  FILE* f = nullptr;
-  explicit File(const char* path) { f = fopen(path, "wb"); }
-  ~File() { if (f) fclose(f); }
-  bool put(const void* p, size_t n) { return n == 0 || fwrite(p, 1, n, f) == n; }
+  int f = -1;  // (tested by the callers: < 0 = not open)
+  std::vector<uint8_t>& buf;
+  static std::vector<uint8_t>& thread_buffer() { thread_local std::vector<uint8_t> b; return b; }
+  explicit File(const char* path) : buf(thread_buffer()) {
+    f = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    buf.clear();
+  }
+  ~File() { if (f >= 0) close(f); }
+  bool put(const void* p, size_t n) {
+    if (n) buf.insert(buf.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n);
+    return buf.size() < (16u << 20) || flush();  // (large step outputs go out in 16 MB pieces)
+  }
+  bool flush() {  // everything so far -> the file
+    const uint8_t* p = buf.data();
+    size_t left = buf.size();
+    while (left) {
+      const ssize_t got = write(f, p, left);
+      if (got < 0) { if (errno == EINTR) continue; return false; }
+      p += got;
+      left -= (size_t)got;
+    }
+    buf.clear();
+    return true;
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ deflate for label images
@@ -250,7 +278,7 @@ int aliby_parquet_write(const char* path, const aliby_pq_column* cols, int n_col
     if (use_zstd && !zstd().ok) { aliby_set_error("parquet_write: zstd compression asked for but libzstd.so.1 is not on this machine"); return ALIBY_ERR_UNSUPPORTED; }
     void* cctx = use_zstd ? thread_cctx() : nullptr;
     File out(path);
-    if (!out.f) { aliby_set_error("parquet_write: cannot open %s for writing", path); return ALIBY_ERR_INVALID; }
+    if (out.f < 0) { aliby_set_error("parquet_write: cannot open %s for writing", path); return ALIBY_ERR_INVALID; }
     if (!out.put("PAR1", 4)) { aliby_set_error("parquet_write: write to %s failed", path); return ALIBY_ERR_INVALID; }
     int64_t offset = 4;
 
@@ -394,7 +422,7 @@ int aliby_parquet_write(const char* path, const aliby_pq_column* cols, int n_col
     std::vector<uint8_t> tail;
     le32(tail, (uint32_t)meta.size());
     tail.insert(tail.end(), {'P', 'A', 'R', '1'});
-    if (!out.put(meta.data(), meta.size()) || !out.put(tail.data(), tail.size()) || fflush(out.f) != 0) {
+    if (!out.put(meta.data(), meta.size()) || !out.put(tail.data(), tail.size()) || !out.flush()) {
       aliby_set_error("parquet_write: write to %s failed", path);
       return ALIBY_ERR_INVALID;
     }
@@ -411,7 +439,7 @@ int aliby_npz_write(const char* path, const aliby_npy_member* members, int n_mem
   ARG_CHECK(level >= 0 && level <= 9, "npz_write: deflate level 0..9");
   try {
     File out(path);
-    if (!out.f) { aliby_set_error("npz_write: cannot open %s for writing", path); return ALIBY_ERR_INVALID; }
+    if (out.f < 0) { aliby_set_error("npz_write: cannot open %s for writing", path); return ALIBY_ERR_INVALID; }
     struct Entry { std::string name; uint32_t crc; uint64_t comp, uncomp, offset; };
     std::vector<Entry> entries;
     std::vector<uint8_t> raw, comp, head;
@@ -505,12 +533,32 @@ int aliby_npz_write(const char* path, const aliby_npy_member* members, int n_mem
     le32(cd, 0x06054b50u);
     le16(cd, 0); le16(cd, 0); le16(cd, (uint16_t)entries.size()); le16(cd, (uint16_t)entries.size());
     le32(cd, (uint32_t)cd_size); le32(cd, (uint32_t)offset); le16(cd, 0);
-    if (!out.put(cd.data(), cd.size()) || fflush(out.f) != 0) { aliby_set_error("npz_write: write to %s failed", path); return ALIBY_ERR_INVALID; }
+    if (!out.put(cd.data(), cd.size()) || !out.flush()) { aliby_set_error("npz_write: write to %s failed", path); return ALIBY_ERR_INVALID; }
     return ALIBY_OK;
   } catch (const std::exception& e) {
     aliby_set_error("npz_write: %s", e.what());
     return ALIBY_ERR_INVALID;
   }
+}
+
+int aliby_host_copy(void* dst, const void* src, size_t bytes, int threads) {
+  ARG_CHECK((dst && src) || bytes == 0, "host_copy: null argument");
+  threads = std::max(1, std::min(threads, 16));
+  const size_t piece = ((bytes + threads - 1) / threads + 4095) & ~(size_t)4095;  // whole pages: a page is first touched by one thread
+  if (threads == 1 || bytes < (8u << 20)) { memcpy(dst, src, bytes); return ALIBY_OK; }
+  try {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) {
+      const size_t lo = std::min(bytes, piece * t), hi = std::min(bytes, piece * (t + 1));
+      if (hi > lo) pool.emplace_back([=] { memcpy(static_cast<uint8_t*>(dst) + lo, static_cast<const uint8_t*>(src) + lo, hi - lo); });
+    }
+    memcpy(dst, src, std::min(bytes, piece));
+    for (auto& th : pool) th.join();
+  } catch (const std::exception& e) {
+    aliby_set_error("host_copy: %s", e.what());
+    return ALIBY_ERR_INVALID;
+  }
+  return ALIBY_OK;
 }
 
 int aliby_host_codecs(int* have_zstd, int* have_libdeflate) {

@@ -43,3 +43,14 @@ def usable_cores(default_cap: int = 16) -> int:
 def describe() -> dict:
     return {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
             "cgroup_quota": _cgroup_quota(), "usable": usable_cores()}
+
+
+def cpu_stat() -> dict:
+    """The cgroup's CPU accounting (usage_usec, nr_periods, nr_throttled, throttled_usec ...), {} where there is none: a process
+    group that runs into its quota is stopped for the rest of the period — every thread, the launch thread included."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            return {k: int(v) for k, v in (line.split()[:2] for line in open(path).read().splitlines() if line.strip())}
+        except (OSError, ValueError):
+            continue
+    return {}

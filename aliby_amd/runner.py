@@ -55,22 +55,29 @@ def _signature(pipeline: dict):
             pipeline.get("save_interval", 1))
 
 
+_STEPS: list = []  # [(init_step_fn, step_name, parameters snapshot, fn)], most recently used last
+
+
 class _SharedSteps:
     """Step objects that hold no per-position state (segmenters: the network and its workspaces; extract partials) are built
-    once per distinct parameter dict and shared by every position, instead of once per position as N single calls would."""
+    once per distinct parameter dict and shared by every position, instead of once per position as N single calls would —
+    and kept for the next run_positions call of the process (a segmenter is ~50 ms of weight packing and workspace allocation:
+    a plate processed as one call per well would pay it per well).  The last 8 are kept; `release_pinned()` drops them."""
 
     def __init__(self, init_step_fn):
         self.init_step_fn = init_step_fn
-        self._made = []  # [(step_name, parameters snapshot, fn)]
 
     def get(self, step_name, parameters, other):
         if step_name.startswith("tile") or step_name.startswith("track"):
             return self.init_step_fn(step_name, parameters, other)  # per-position state (the image, the running labels)
-        for name, params, fn in self._made:
-            if name == step_name and params == parameters:
+        for k in range(len(_STEPS) - 1, -1, -1):
+            maker, name, params, fn = _STEPS[k]
+            if maker is self.init_step_fn and name == step_name and params == parameters:
+                _STEPS.append(_STEPS.pop(k))
                 return fn
         fn = self.init_step_fn(step_name, parameters, other)
-        self._made.append((step_name, dict(parameters), fn))
+        _STEPS.append((self.init_step_fn, step_name, dict(parameters), fn))
+        del _STEPS[:-8]
         return fn
 
 
@@ -87,31 +94,44 @@ class _LazyRows:
         with self._lock:
             if self._rows is None:
                 rows = self.download.wait(spin=False)[self.index][self.lo : self.hi]  # (None : None = the whole block)
-                self._rows = np.array(rows) if self.copy else rows
+                if self.copy and rows.flags.c_contiguous and rows.nbytes >= (8 << 20):
+                    # ~130 MB per batch, with every writer thread of the batch waiting for the table built on it: 4 threads
+                    from aliby_amd import _lib
+
+                    out = np.empty_like(rows)
+                    _lib.check(_lib.load().aliby_host_copy(out.ctypes.data, rows.ctypes.data, rows.nbytes, 4))
+                    rows = out
+                elif self.copy:
+                    rows = np.array(rows)
+                self._rows = rows
                 self.download = None
             return self._rows
 
 
 class _Arena:
-    """One page-locked block, bump-allocated by a batch and handed back when the batch's last position is on disk.
-    hipHostMalloc of the ~400 MB a 64-position batch downloads (labels, feature rows twice) takes tens of ms on the launch
-    thread; three arenas are allocated once and go round."""
+    """Page-locked memory of one batch in flight: bump-allocated by the batch, handed back when the batch's last position is on
+    disk.  hipHostMalloc of the ~400 MB a 64-position batch downloads (labels, feature rows twice) takes tens of ms on the
+    launch thread, so nothing is ever given back: a request that does not fit the chunks the arena has gets a new chunk, and
+    the next batch — the same requests in the same order — walks through the same chunks.  Three arenas go round."""
 
     def __init__(self, ring):
-        self.ring, self.buf, self.used, self.left = ring, None, 0, 0
+        self.ring, self.left = ring, 0
+        self.chunks, self.chunk, self.used = [], 0, 0  # page-locked uint8 tensors / the one being filled / bytes used of it
 
     def alloc(self, shape, dtype):
         import torch
 
         n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
-        start = (self.used + 255) & ~255
-        if self.buf is None or start + n > self.buf.numel():
-            if self.used == 0 or self.buf is None:  # grow (first batches only); a partly used arena falls back to a loose buffer
-                self.buf = torch.empty(int((start + n) * 1.3) + (1 << 20), dtype=torch.uint8, pin_memory=True)
-            else:
-                return torch.empty(shape, dtype=dtype, pin_memory=True)
-        self.used = start + n
-        return self.buf[start : start + n].view(dtype).view(shape)
+        while True:
+            if self.chunk == len(self.chunks):
+                trace.mark(f"arena: new chunk for {n} bytes")
+                self.chunks.append(torch.empty(int(n * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True))
+                self.used = 0
+            start = (self.used + 255) & ~255
+            if start + n <= self.chunks[self.chunk].numel():
+                self.used = start + n
+                return self.chunks[self.chunk][start : start + n].view(dtype).view(shape)
+            self.chunk, self.used = self.chunk + 1, 0
 
     def retire(self):
         """One position of the batch is done; the last one frees the arena."""
@@ -119,7 +139,7 @@ class _Arena:
             self.left -= 1
             if self.left > 0:
                 return
-            self.used = 0
+            self.chunk = self.used = 0
             self.ring.free.append(self)
             self.ring.lock.notify()
 
@@ -165,11 +185,14 @@ def _shared_ring():
 
 
 def release_pinned():
-    """Give back the page-locked memory `run_positions` keeps between calls."""
+    """Give back what `run_positions` keeps between calls: the page-locked arenas and the shared step objects (segmenters with
+    their device workspaces)."""
     _RINGS.clear()
+    _STEPS.clear()
 
 
 _Product = ex.LazyProduct
+_ABLATE = os.environ.get("ALIBY_ABLATE", "")
 
 
 class _Phase:
@@ -370,7 +393,7 @@ class BatchRunner:
         for pos, nt in zip(batch, tiles_of):
             lo, hi = int(table.offsets[t0]), int(table.offsets[t0 + nt])
             rows = table.host[lo:hi]
-            objects = [(int(t) - t0, int(l)) for t, l in zip(rows["tile"], rows["label"])]
+            objects = list(zip((rows["tile"] - t0).tolist(), rows["label"].tolist()))
             bounds.append((lo, hi))
             every.append(objects)
             t0 += nt
@@ -380,7 +403,14 @@ class BatchRunner:
         # (Only one-timepoint runs pivot the batch at once: a time-lapse downloads its rows once per timepoint, as they are.)
         alloc = self._arena.alloc if self._arena is not None else None
         if batch[0].pipeline.get("ntps", 1) == 1 and tp == 0:
-            flat = [o for objs in every for o in objs]
+            # (tile, label) of every row of the batch, tiles counted from each position's first: an int64 [n, 2] array, not
+            # 16 k tuples — _format_dense wants exactly that array
+            flat = np.empty((bounds[-1][1] if bounds else 0, 2), np.int64)
+            t0 = 0
+            for (lo, hi), nt in zip(bounds, tiles_of):
+                flat[lo:hi, 0] = table.host["tile"][lo:hi] - t0
+                flat[lo:hi, 1] = table.host["label"][lo:hi]
+                t0 += nt
             whole = ex.DeviceResults(None, flat, instructions, blocks)
             _, take = ex._dense_layout(whole)
             sorted_t = matrix.index_select(1, torch.as_tensor(take, device=matrix.device)).t().contiguous() if matrix.shape[0] else matrix.t()
@@ -398,7 +428,7 @@ class BatchRunner:
     def _save(self, pos, step_name, result, tp):
         wanted = pos.pipeline.get("save") or []
         every = pos.pipeline.get("save_interval", 1)
-        if wanted and every > 0 and tp % every == 0 and step_name in wanted:
+        if wanted and every > 0 and tp % every == 0 and step_name in wanted and _ABLATE != "files":
             if self.measure is not None:
                 with self._timed("write: step outputs (.npz, zlib)"):
                     dispatch_write_fn(step_name)(result, steps_dir=pos.steps_dir, subpath=step_name, tp=tp)  # (_timed drained the device)
@@ -448,8 +478,10 @@ class BatchRunner:
         import time
 
         t0 = time.perf_counter()
+        trace.mark("w:npz begin")
         _wait_host(result)  # the batched segmenter downloads labels asynchronously
         fn(result, steps_dir=steps_dir, subpath=step_name, tp=tp)
+        trace.mark("w:npz end")
         self._tick("step outputs (.npz)", t0)
 
     def prepare(self, batch):
@@ -532,7 +564,7 @@ class BatchRunner:
         names = [n for n in steps if n.startswith("extract") or n.startswith("nahual_embed")]
         whole = None
         if ntps == 1 and names and all(n in dense for n in names):
-            whole = _Once(lambda: self._profiles_for_batch(batch, names, dense))  # one pivot + join for the batch, on a writer thread
+            whole = _Once(lambda: self._profiled_pivot(batch, names, dense))  # one pivot + join for the batch, on a writer thread
         if not self._flushed:
             self.flush_submits()  # no long device wait in this batch's steps (no segmenter): nothing to hide the hand-over behind
         if self.measure is not None:
@@ -547,6 +579,20 @@ class BatchRunner:
         got = whole.get()
         if got is not None and got[1] is not None:
             got[1].get()
+
+    def _profiled_pivot(self, batch, names, dense):
+        if not os.environ.get("ALIBY_PROFILE_PIVOT"):
+            return self._profiles_for_batch(batch, names, dense)
+        import cProfile
+        import pstats
+        import sys
+
+        prof = cProfile.Profile()
+        out = prof.runcall(self._profiles_for_batch, batch, names, dense)
+        self._pivots = getattr(self, "_pivots", 0) + 1
+        if self._pivots == 6:  # (one steady-state batch is enough)
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(30)
+        return out
 
     def _profiles_for_batch(self, batch, names, dense):
         """get_profiles_from_state (pipe_core.py:453-512) for every position of a one-timepoint batch at once: each extract
@@ -667,15 +713,22 @@ class BatchRunner:
         import time
 
         t0 = time.perf_counter()
+        trace.mark("w:finish begin")
         got = whole.get() if whole is not None else None
+        trace.mark("w:pivot there")
         self._tick("batch pivot (one thread works, the others wait)", t0)
         joined, ipc, layouts = got if got is not None else (None, None, None)
+        if _ABLATE == "files":  # diagnostic: no per-position work at all (what the launch thread does when left alone)
+            pos.state = pos.engine = None
+            return None, {}
         written = False
         if joined is not None:
             import pyarrow as pa
 
+            t0 = time.perf_counter()
             parts = [t.slice(b[k][0], b[k][1] - b[k][0]) for t, b in joined if b[k][1] > b[k][0]]
-            profiles = pa.concat_tables(parts) if parts else pipe_core._empty_profiles()
+            profiles = (parts[0] if len(parts) == 1 else pa.concat_tables(parts)) if parts else pipe_core._empty_profiles()
+            self._tick("position's table: slices of the batch table", t0)
             if layouts is not None and parts:
                 t0 = time.perf_counter()
                 with self._timed("write: parquet (zstd)"):
@@ -711,7 +764,10 @@ class BatchRunner:
         for f in pos.pending:
             f.result()
         self._tick("waiting for this position's step outputs", t0)
+        t0 = time.perf_counter()
         pos.state = pos.engine = None  # releases the device blocks of this position
+        self._tick("releasing the position's state", t0)
+        trace.mark("w:finish end")
         return profiles, {}
 
     def close(self):
@@ -866,7 +922,29 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
         if switch_interval is not None:
             sys.setswitchinterval(min(interval, switch_interval))
         nxt = None
-        clock = {"wait_ingest_s": 0.0, "device_steps_s": 0.0, "drain_writers_s": 0.0}
+        clock = {"wait_ingest_s": 0.0, "device_steps_s": 0.0, "drain_writers_s": 0.0, "gc_s": 0.0}
+        # The cycle collector starts when allocation counts say so — in the middle of the ~25 ms per batch in which the launch
+        # thread is what the device waits for — and a full collection walks everything torch / pyarrow / numpy ever imported:
+        # measured as one 100 ms hole in every few batches (value_api 455 -> 477 tiles/s without it).  While the call runs the
+        # objects that exist now are frozen out of the collector's sight, automatic collection is off, and the launch thread
+        # collects by hand each time it is about to sleep behind a whole network forward (trace.about_to_block), or at the end
+        # of a batch that had no such wait.  ALIBY_MANAGE_GC=0 leaves the collector alone.
+        import gc
+
+        manage_gc = gc.isenabled() and not measure and os.environ.get("ALIBY_MANAGE_GC", "1") != "0"
+        collected = [False]
+
+        def collect():
+            t0 = time.perf_counter()
+            gc.collect()
+            collected[0] = True
+            clock["gc_s"] += time.perf_counter() - t0
+
+        if manage_gc:
+            gc.collect()
+            gc.freeze()
+            gc.disable()
+            trace.BEFORE_BLOCK.append(collect)
         for b, batch in enumerate(batches):
             t0 = time.perf_counter()
             if measure:
@@ -878,7 +956,10 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
                 (nxt or runner.ingest.submit(prepare, batch)).result()
                 nxt = runner.ingest.submit(prepare, batches[b + 1]) if b + 1 < len(batches) else None
             t1 = time.perf_counter()
+            collected[0] = False
             futures.extend(zip(batch, runner.run_batch(batch)))
+            if manage_gc and not collected[0]:
+                collect()
             t2 = time.perf_counter()
             clock["wait_ingest_s"] += t1 - t0
             clock["device_steps_s"] += t2 - t1
@@ -898,6 +979,11 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
     finally:
         runner.close()
         try:
+            if manage_gc:
+                if collect in trace.BEFORE_BLOCK:
+                    trace.BEFORE_BLOCK.remove(collect)
+                gc.enable()
+                gc.unfreeze()
             sys.setswitchinterval(interval)
         except NameError:
             pass

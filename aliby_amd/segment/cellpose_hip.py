@@ -273,6 +273,7 @@ class CellposeModel:
             self.eng, dP, prob, niter=200 if niter is None else niter, cellprob_threshold=cellprob_threshold,
             flow_threshold=flow_threshold, min_size=min_size, max_size_fraction=max_size_fraction,
         )
+        dynamics._mark("eval:dynamics returned")
         self.last_counts = counts
         masks = labels[0] if labels.shape[0] == 1 else labels
         return masks, [None, dP, prob], None

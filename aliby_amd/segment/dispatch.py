@@ -16,6 +16,7 @@ from __future__ import annotations
 import numpy as np
 
 from aliby_amd import devcache
+from aliby_amd import trace as _trace
 
 
 def _to_uint16_labels(labels: np.ndarray) -> np.ndarray:
@@ -94,6 +95,7 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
             plane = planes[0] if len(planes) == 1 else torch.cat(planes, 0)
         result = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=kw.pop("normalize", True), z_axis=None, **kw)
         labels = result[0]
+        _trace.mark("segment:eval returned")
         return (labels if labels.ndim == 3 else labels[None]), np.asarray(model.last_counts)
 
     def _finish(stack, counts, host_stack=None, ready=None):
@@ -154,6 +156,7 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         reference's post-processing on its own.  Returns one step result per position, identical to `segment(block)`."""
         devs = [_device_block(b) for b in blocks]
         stack, counts = _labels_of(devs, dict(kw))
+        _trace.mark("segment:labels_of returned")
         # every position's labels in ONE download through a page-locked buffer (N pageable copies cost a sync each)
         import torch
 
@@ -162,10 +165,21 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         # (a fresh page-locked buffer costs a hipHostMalloc of ~100 MB per batch on the launch thread: the runner lends its arena)
         pinned = (pinned_alloc(tuple(stack.shape), stack.dtype) if pinned_alloc is not None
                   else torch.empty(tuple(stack.shape), dtype=stack.dtype, pin_memory=True))  # (its NumPy views keep it alive)
-        pinned.copy_(stack, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
+        _trace.mark("segment:labels ready")
+        # on a side stream: 134 MB for 64 frames is ~3 ms of PCIe time the feature kernels would otherwise queue behind
+        side = getattr(segment_batch, "_copy_stream", None)
+        if side is None:
+            side = segment_batch._copy_stream = torch.cuda.Stream()
+        done = torch.cuda.Event()
+        done.record()
+        side.wait_event(done)
+        with torch.cuda.stream(side):
+            pinned.copy_(stack, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        stack.record_stream(side)
         host_all = pinned.numpy()
+        _trace.mark("segment:download queued")
         out, k = [], 0
         for d in devs:
             f = d.shape[0]

@@ -20,3 +20,4 @@ BEFORE_BLOCK: list = []
 def about_to_block() -> None:
     for hook in list(BEFORE_BLOCK):
         hook()
+

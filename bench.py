@@ -313,7 +313,7 @@ def main():
                     "runs as a replayed hipGraph (the product path); the line then carries no roofline objects")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the through-the-step-API leg (value_api)")
-    ap.add_argument("--api-fovs", type=int, default=0, help="positions of the API leg (default: 8 batches of --fovs)")
+    ap.add_argument("--api-fovs", type=int, default=0, help="positions of the API leg (default: 16 batches of --fovs ~ a 384-well plate at 2-3 fields per well)")
     ap.add_argument("--overlap", action="store_true", help="experiment: dynamics + features of step k on a second stream while the "
                     "network of step k+1 runs (software pipelining across steps)")
     ap.add_argument("--inputs", default="", help="path prefix of an input cache (<prefix>.r<rank>of<world>.npz): loaded when present, "
@@ -589,7 +589,7 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
     from aliby_amd import runner
     from aliby_amd.pipe_builder import build_pipeline_steps
 
-    n_pos = args.api_fovs or 8 * B  # (>= 4 batches: run_positions then writes parquet from worker processes)
+    n_pos = args.api_fovs or 16 * B  # (fill and drain of the pipeline, ~50 + ~65 ms, are part of the timed region)
     dev = torch.device("cuda", torch.cuda.current_device())
     dP_d = torch.stack([torch.from_numpy(b["dP"]) for b in base]).to(dev)
     prob_d = torch.stack([torch.from_numpy(b["prob"]) for b in base]).to(dev)
@@ -630,6 +630,9 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
                 dist.barrier()
             names = [f"p{rank}_{i:05d}" for i in range(n_pos)]
             pipes = pipelines(n_pos)
+            from aliby_amd import hostinfo
+
+            cpu0 = hostinfo.cpu_stat()
             t0 = time.perf_counter()
             stats = {}
             prof = None
@@ -646,8 +649,10 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
                 pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            rows = sum(r[0].num_rows for r in res)
-            cols = len(res[0][0].column_names)
+            cpu1 = hostinfo.cpu_stat()
+            stats["cgroup_cpu"] = {k: cpu1[k] - cpu0.get(k, 0) for k in cpu1 if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")}
+            rows = sum(r[0].num_rows for r in res if r[0] is not None)  # (None: ALIBY_ABLATE diagnostics)
+            cols = len(res[0][0].column_names) if res[0][0] is not None else 0
             if dist is not None:
                 t = torch.tensor([dt], dtype=torch.float64, device="cuda")
                 if backend != "nccl":

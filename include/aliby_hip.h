@@ -530,6 +530,13 @@ int aliby_npz_write(const char* path, const aliby_npy_member* members, int n_mem
 /* which of the two optional codec libraries were found on this machine */
 int aliby_host_codecs(int* have_zstd, int* have_libdeflate);
 
+/* memcpy of a large host block on `threads` threads (1..16; blocks under 8 MB are copied by the caller's thread): the
+ * position-batched runner takes a batch's feature rows (~130 MB) out of its page-locked download arena into memory the returned
+ * tables own — one thread pays ~12 ms for that, mostly first-touch page faults, while every writer thread of the batch waits for
+ * the table (aliby_amd/runner.py _LazyRows; the reference has no such copy: extract.py:520-599 builds its table from Python
+ * lists). */
+int aliby_host_copy(void* dst, const void* src, size_t bytes, int threads);
+
 #ifdef __cplusplus
 }
 #endif

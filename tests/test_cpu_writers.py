@@ -134,3 +134,19 @@ def test_native_writers_can_be_switched_off(tmp_path, monkeypatch):
     W.write_profiles(t, tmp_path / "p.parquet")
     assert pq.read_metadata(tmp_path / "p.parquet").created_by.startswith("parquet-cpp")
     _equal_tables(pq.read_table(tmp_path / "p.parquet"), t)
+
+
+def test_host_copy_on_several_threads_is_a_memcpy():
+    """aliby_host_copy: sizes around the 8 MB threshold and the page-rounded piece boundaries, 1..16 threads, odd byte counts."""
+    import numpy as np
+
+    from aliby_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for nbytes in (0, 1, 4095, (8 << 20) - 1, (8 << 20) + 1, (9 << 20) + 12345):
+        src = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        for threads in (1, 3, 4, 16, 99):
+            dst = np.zeros(nbytes + 8, np.uint8)
+            _lib.check(lib.aliby_host_copy(dst.ctypes.data, src.ctypes.data, nbytes, threads))
+            assert np.array_equal(dst[:nbytes], src) and not dst[nbytes:].any()
