@@ -513,7 +513,11 @@ class BatchRunner:
                 ready = torch.cuda.Event()
                 ready.record(self._h2d_stream)
         batch[0].prefetched = (first, results, ready)
-        trace.mark("prepare:end (ingest thread)")
+        if trace.MARKS is not None:
+            st = torch.cuda.memory_stats()
+            trace.mark(f"prepare:end (ingest thread) device mallocs so far {st.get('num_device_alloc', 0)}, reserved {st.get('reserved_bytes.all.current', 0) >> 20} MiB")
+        else:
+            trace.mark("prepare:end (ingest thread)")
 
     def run_batch(self, batch):
         """All timepoints of a batch of positions with one signature.  Returns one future per position -> (profiles, {})."""
@@ -941,8 +945,7 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
             clock["gc_s"] += time.perf_counter() - t0
 
         if manage_gc:
-            gc.collect()
-            gc.freeze()
+            gc.freeze()  # (no collection first: a full one is 50-100 ms with torch and pyarrow imported, and unfreeze undoes this)
             gc.disable()
             trace.BEFORE_BLOCK.append(collect)
         for b, batch in enumerate(batches):

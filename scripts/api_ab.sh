@@ -38,6 +38,7 @@ allm = sorted(m["trace"], key=lambda x: x[1])
 tr = [(lab, t) for lab, t in allm if "ingest thread" not in lab and not lab.startswith("w:")]
 idx = [i for i, (lab, t) in enumerate(tr) if lab == "run_batch:arena acquired"] + [len(tr)]
 print("gc_s", m.get("gc_s"), "drain", m["drain_writers_s"])
+print([lab for lab, t in allm if lab.startswith("prepare:end")])
 cols = ["dynamics:call", "dynamics:returned", "object_table:call", "extract_nuclei:returned", "extractmulti_nuclei:returned", "batch:steps done"]
 print("batch  period | " + " | ".join(c[:22] for c in cols) + " | other marks")
 for a, b in zip(idx, idx[1:]):

@@ -469,3 +469,54 @@ def test_dense_layout_cache_keeps_renamed_columns_apart():
     assert c3.isdisjoint(c5), sorted(c3 & c5)[:3]
     assert all("_3_" in c for c in c3) and all("_5_" in c for c in c5)
     assert tables[1]["0/max/texture/" + texture_names(5)[0]].to_pylist() == [5.0, 5.0 + len(texture_names(5))]
+
+
+def test_run_positions_keeps_shared_steps_between_calls_and_leaves_the_collector_as_it_found_it(tmp_path):
+    """Host-only stand-in steps (no GPU): a step object without per-position state is built once for the process, not once per
+    call or per position (aliby_amd/runner.py _SharedSteps); `release_pinned()` drops it; while a call runs the cycle collector is
+    off (the launch thread collects by hand), afterwards it is back on, nothing stays frozen, and a failing step restores it too."""
+    import gc
+
+    from aliby_amd import runner
+
+    made, seen = [], []
+
+    class FakeTiler:
+        def __init__(self, k):
+            self.k = k
+
+        def run_tp(self, tp):
+            return {"drift": {}, "pixels": np.full((1, 1, 1, 4, 4), self.k, np.uint16)}
+
+    def init(step_name, parameters, other=None):
+        made.append(step_name)
+        if step_name == "tile":
+            return FakeTiler(parameters["k"])
+
+        def embed(pixels):
+            seen.append(gc.isenabled())
+            if parameters.get("fail"):
+                raise RuntimeError("boom")
+            return np.arange(6, dtype=np.float64).reshape(2, 3) + float(pixels.flat[0])
+
+        return embed
+
+    def pipes(n, **extra):
+        return [{"steps": {"tile": {"k": i}, "nahual_embed_x": {"address": "ipc://unused", **extra}},
+                 "passed_data": {"nahual_embed_x": [("pixels", "tile")]}} for i in range(n)]
+
+    runner.release_pinned()
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    for call in range(2):
+        got = runner.run_positions(pipes(3), [f"c{call}_{i}" for i in range(3)], tmp_path / "out", init_step_fn=init, batch_size=2)
+        assert [g[0].num_rows for g in got] == [2, 2, 2]
+        assert gc.isenabled() and gc.get_freeze_count() == 0
+    assert made.count("nahual_embed_x") == 1 and made.count("tile") == 6  # the embedder: once; tilers hold an image each
+    assert seen and not any(seen)  # the steps ran with the collector off
+    runner.release_pinned()
+    runner.run_positions(pipes(1), ["again"], tmp_path / "out", init_step_fn=init, batch_size=2)
+    assert made.count("nahual_embed_x") == 2
+    with pytest.raises(RuntimeError, match="boom"):
+        runner.run_positions(pipes(1, fail=True), ["bad"], tmp_path / "out", init_step_fn=init, batch_size=2)
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    runner.release_pinned()
