@@ -213,15 +213,22 @@ class FeatureEngine:
         return out
 
     # ------------------------------------------------------------------ objects
-    def object_table(self, labels: torch.Tensor) -> ObjectTable:
+    def object_table(self, labels: torch.Tensor, max_labels=None) -> ObjectTable:
+        """max_labels: the largest label of every frame when the caller knows it (the segmenter's object counts: its labels are
+        1..n) — saves the pass over the label block that finds it and the host synchronisation behind that pass."""
         F, Y, X = labels.shape
         lib, h = self.lib, self.ctx.handle
-        mx = np.zeros(F, np.int32)
         from aliby_amd import trace
 
         trace.mark("object_table:call")
-        with self.timed("object_table"):
-            _lib.check(lib.aliby_label_max(h, _ptr(labels), F, Y, X, _ptr(mx), _stream_ptr()))
+        if max_labels is not None:
+            mx = np.ascontiguousarray(max_labels, dtype=np.int32)
+            if mx.shape != (F,) or (mx < 0).any():
+                raise ValueError(f"max_labels must hold one non-negative count per frame ({F}), got shape {mx.shape}")
+        else:
+            mx = np.zeros(F, np.int32)
+            with self.timed("object_table"):
+                _lib.check(lib.aliby_label_max(h, _ptr(labels), F, Y, X, _ptr(mx), _stream_ptr()))
         offsets = np.zeros(F + 1, np.int32)
         np.cumsum(mx, out=offsets[1:])
         n_obj = int(offsets[-1])

@@ -367,10 +367,13 @@ class BatchRunner:
         tree = params[0]["tree"]
         cp_kwargs = params[0].get("kwargs", {}).get("cp_measure_kwargs") or {}
         instructions = ex.kv(ex.flatten(tree))
-        labels, pixels, tiles_of = [], [], []
+        labels, pixels, tiles_of, known = [], [], [], []
         for inp in inputs:
             masks = inp["masks"] if isinstance(inp["masks"], list) else [inp["masks"]]
             lab = ex._stack_masks(masks)
+            for m in masks:  # the segmenter registers each frame's object count (= its largest label) with the device copy
+                hit = devcache.lookup(m) if isinstance(m, np.ndarray) else None
+                known.append(hit[1].get("max_label") if hit is not None and hit[0].ndim == 2 else None)
             px, dt = ex._device_pixels(inp["pixels"])
             if lab.shape[0] != px.shape[0] and lab.shape[0] != 1:
                 return None
@@ -386,7 +389,8 @@ class BatchRunner:
         key = (tuple(l.data_ptr() for l in labels), tuple(lab_all.shape))
         hit = self._tables.get(key)
         if hit is None:
-            hit = self._tables[key] = (eng.object_table(lab_all), labels)  # (the label tensors are kept so the key stays theirs)
+            mx = known if len(known) == lab_all.shape[0] and all(k is not None for k in known) else None
+            hit = self._tables[key] = (eng.object_table(lab_all, max_labels=mx), labels)  # (the label tensors are kept so the key stays theirs)
         table = hit[0]
         matrix, blocks = families.evaluate(eng, lab_all, table, (px_all, pixels[0][1]), instructions, cp_kwargs, multi=multi)
         out, t0, bounds, every = [], 0, [], []

@@ -105,7 +105,7 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
             if counts.size and counts.max() >= np.iinfo(np.uint16).max:
                 raise OverflowError(f"Segmentation produced {counts.max()} labels; uint16 cast unsafe.")
             host = stack.cpu().numpy() if host_stack is None else host_stack
-            return [devcache.attach(host[k], stack[k], kind="labels", ready=ready) for k in range(host.shape[0])]
+            return [devcache.attach(host[k], stack[k], kind="labels", ready=ready, max_label=int(counts[k])) for k in range(host.shape[0])]
         if stack.shape[0] > 1:
             # reference: a 3-D result is collapsed, labels.max(axis=0) then relabel_sequential (dispatch.py:218-223)
             labels_dev = model.max_project_and_relabel(stack)
@@ -116,8 +116,8 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
         if n_labels >= np.iinfo(np.uint16).max:
             raise OverflowError(f"Segmentation produced {n_labels} labels; uint16 cast unsafe.")
         if host_stack is not None and stack.shape[0] == 1:
-            return devcache.attach(host_stack[0], labels_dev, kind="labels", ready=ready)
-        return devcache.attach(labels_dev.cpu().numpy(), labels_dev, kind="labels")
+            return devcache.attach(host_stack[0], labels_dev, kind="labels", ready=ready, max_label=n_labels)
+        return devcache.attach(labels_dev.cpu().numpy(), labels_dev, kind="labels", max_label=n_labels)
 
     def segment(pixels, do_3D: bool = False, stitch_threshold=None, **kw):
         """Assumes FCZYX pixels.  Returns uint16 labels [Y,X] (monotile), as the reference does."""

@@ -51,6 +51,12 @@ def test_dynamics_bit_exact_vs_oracle(engine, objset):
         want = cr.compute_masks(dP, prob)
         assert got[k].max() == want.max() == n[k]
         assert np.array_equal(got[k], want), f"tile {k}: {int((got[k] != want).sum())} pixels differ"
+    # the counts are the frames' largest labels: handed to the object table they save its own pass (aliby_amd/runner.py does)
+    t_own, t_known = engine.object_table(labels), engine.object_table(labels, max_labels=n)
+    assert np.array_equal(t_own.host, t_known.host) and np.array_equal(t_own.offsets, t_known.offsets)
+    assert torch.equal(t_own.dev[: 32 * t_own.n_obj], t_known.dev[: 32 * t_known.n_obj])
+    with pytest.raises(ValueError, match="one non-negative count per frame"):
+        engine.object_table(labels, max_labels=n[:2])
     # the clean tiles recover the ground-truth partition
     gt = tiles[0][0]
     assert n[0] == gt.max()
