@@ -78,7 +78,7 @@ def alg_bytes(kernel, B, C, Z, Y, X, n_obj, n_tiles_net):
         "make_tiles": B * P * 4 + n_tiles_net * 2 * 224 * 224 * 4,
         "average_tiles": n_tiles_net * 3 * 224 * 224 * 4 + B * 3 * P * 4,
         "dynamics": B * (3 * P * 4 + P * 2),
-        "object_table": 2 * B * P * 2 + n_obj * 32,
+        "object_table": B * P * 2 + n_obj * 32,  # (one pass: the largest labels come from the segmenter's counts)
         "intensity": B * P * 2 * 2 + n_obj * 21 * 8,
         "sizeshape": B * P * 2 + n_obj * 78 * 8,
         "feret": B * P * 2 + n_obj * 2 * 8,
@@ -422,7 +422,8 @@ def main():
         masks, _, _ = model.eval(plane, do_3D=False, stitch_threshold=0.0, normalize=True, z_axis=None)
         labels = masks if masks.ndim == 3 else masks[None]
         planes = (px, _lib.U16)
-        m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
+        # (the segmenter's counts are its frames' largest labels: the object table skips its own pass, as through the API)
+        m1, names1, table = extract_batch(eng, labels, planes, mono_tree, table=eng.object_table(labels, max_labels=model.last_counts))
         out = [m1]
         if multi_tree:
             m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
@@ -459,7 +460,7 @@ def main():
             labels, counts = dynamics.masks_from_flows(eng, dP_true, prob_true, niter=200, cellprob_threshold=0.0, flow_threshold=0.4,
                                                        min_size=15, max_size_fraction=0.4)
             planes = (px, _lib.U16)
-            m1, names1, table = extract_batch(eng, labels, planes, mono_tree)
+            m1, names1, table = extract_batch(eng, labels, planes, mono_tree, table=eng.object_table(labels, max_labels=counts))
             m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
             pending = eng.to_host_async((m1, m2), slot=step.parity)
             step.parity ^= 1
