@@ -281,7 +281,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_deep(DeepArgs a) {
           acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[(f & ~1) % DC_PDEPTH], acc[b], 0, 0, 0);
 #else
           if constexpr (f + DC_PDEPTH - 1 < NF) pring[(f + DC_PDEPTH - 1) % DC_PDEPTH] = pfrag(f + DC_PDEPTH - 1);
-          if constexpr (!(DC_HACK & 1)) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], acc[b], 0, 0, 0);
+          if constexpr (DC_HACK & 128) {  // timing only: the same FLOPs and operand reads as two v_mfma_f32_16x16x32_bf16 (the clock the chip holds depends on the shape)
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            f32x4_t q0 = {acc[b][0], acc[b][1], acc[b][2], acc[b][3]}, q1 = {acc[b][4], acc[b][5], acc[b][6], acc[b][7]};
+            q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], q0, 0, 0, 0);
+            q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], q1, 0, 0, 0);
+            acc[b][0] = q0[0]; acc[b][1] = q0[1]; acc[b][2] = q0[2]; acc[b][3] = q0[3];
+            acc[b][4] = q1[0]; acc[b][5] = q1[1]; acc[b][6] = q1[2]; acc[b][7] = q1[3];
+          } else if constexpr (!(DC_HACK & 1)) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wring[i % DC_WDEPTH], pring[f % DC_PDEPTH], acc[b], 0, 0, 0);
           else { acc[b][0] += (float)(__builtin_bit_cast(uint4, wring[i % DC_WDEPTH]).x + __builtin_bit_cast(uint4, pring[f % DC_PDEPTH]).x); }
 #endif
         });
