@@ -43,12 +43,16 @@ struct DynShape {
 #define FG_CHUNK 4096  // pixels per workgroup pass
 __global__ __launch_bounds__(256) void k_prep_compact(const float* __restrict__ dP, const float* __restrict__ prob, float thr,
                                                       DynShape s, float cx, float cy, float* __restrict__ im,
-                                                      int* __restrict__ list, int* __restrict__ count) {
+                                                      int* __restrict__ list, int* __restrict__ count, int reverse) {
   __shared__ int red_i[8];
   __shared__ int wsum[4];
   __shared__ int s_base;
   const size_t total = (size_t)s.F * s.P;
-  for (size_t c0 = (size_t)blockIdx.x * FG_CHUNK; c0 < total; c0 += (size_t)gridDim.x * FG_CHUNK) {
+  const size_t nchunks = (total + FG_CHUNK - 1) / FG_CHUNK;
+  // (reverse: a test hook, ALIBY_DEBUG_FG_REVERSE=1 — chunks reserve their list space in descending raster order, the order the
+  // scheduler only produces now and then; everything downstream must not care)
+  for (size_t ci = blockIdx.x; ci < nchunks; ci += gridDim.x) {
+    const size_t c0 = (reverse ? nchunks - 1 - ci : ci) * FG_CHUNK;
     unsigned fgmask = 0;
 #pragma unroll
     for (int k = 0; k < FG_CHUNK / 256; ++k) {
@@ -263,13 +267,22 @@ __global__ __launch_bounds__(256) void k_assign(const int* __restrict__ list, co
     const int lane = threadIdx.x & (WAVE - 1);
     const unsigned long long key = ((unsigned long long)f << 32) | lab;
     const unsigned long long prev = __shfl_up(key, 1, WAVE);
-    const bool head = lab && (lane == 0 || prev != key);
+    const int prev_p = __shfl_up(p, 1, WAVE);
+    // (the list is in raster order inside a 4096-pixel chunk of k_prep_compact, and the chunks land in it in the order their
+    // workgroups reserved space: where a wave straddles two chunks the position can step BACK inside a run of one label — a
+    // mask that spans both — and the run's first lane no longer holds its smallest position: such a step starts a new run)
+#ifdef DYN_OLD_HEADS
+    const bool head = lab && (lane == 0 || prev != key);  // (the round-3 bug, kept to show that the test below catches it)
+    (void)prev_p;
+#else
+    const bool head = lab && (lane == 0 || prev != key || prev_p > p);
+#endif
     const unsigned long long heads = __ballot(head || !lab) | ~__ballot(1);
     if (head) {
       const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
       const int run = after ? __ffsll((long long)after) : 64 - lane;
       atomicAdd(&cnt[f * s.PP + lab - 1], run);
-      atomicMin(&firstpos[f * s.PP + lab - 1], p);  // (the list is in raster order inside a wave: the head is the run's first position)
+      atomicMin(&firstpos[f * s.PP + lab - 1], p);  // (positions ascend inside a run: the head holds the run's first)
     }
   }
 }
@@ -685,7 +698,9 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
   HIP_TRY(hipMemsetAsync(labels_out, 0, sizeof(u16) * totP, s));
   HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(5 * F + 8), s));
   const float cx = 2.0f / (float)(X - 1), cy = 2.0f / (float)(Y - 1);
-  hipLaunchKernelGGL(k_prep_compact, dim3(gP), dim3(256), 0, s, dP, cellprob, cellprob_threshold, sh, cx, cy, im, fg_list, fg_count);
+  const char* rev_env = getenv("ALIBY_DEBUG_FG_REVERSE");
+  const int rev = rev_env && atoi(rev_env) ? 1 : 0;  // (one workgroup then: it walks the chunks last to first, so that is their order in the list)
+  hipLaunchKernelGGL(k_prep_compact, dim3(rev ? 1 : gP), dim3(256), 0, s, dP, cellprob, cellprob_threshold, sh, cx, cy, im, fg_list, fg_count, rev);
   KERNEL_CHECK();
   hipLaunchKernelGGL(k_follow, dim3(gP), dim3(256), 0, s, im, fg_list, fg_count, sh, niter, ptc, h1, M1, p_final_out);
   KERNEL_CHECK();

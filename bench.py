@@ -423,10 +423,22 @@ def main():
         labels = masks if masks.ndim == 3 else masks[None]
         planes = (px, _lib.U16)
         # (the segmenter's counts are its frames' largest labels: the object table skips its own pass, as through the API)
-        m1, names1, table = extract_batch(eng, labels, planes, mono_tree, table=eng.object_table(labels, max_labels=model.last_counts))
+        table = eng.object_table(labels, max_labels=model.last_counts)
+        # the colocalisation tree (rank planes + one launch for all pairs) on a stream of its own beside the per-channel families
+        m2 = None
+        if multi_tree and step.side is not None:
+            main = torch.cuda.current_stream()
+            step.side.wait_stream(main)
+            with torch.cuda.stream(step.side):
+                m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+        m1, names1, _ = extract_batch(eng, labels, planes, mono_tree, table=table)
         out = [m1]
         if multi_tree:
-            m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+            if m2 is None:
+                m2, names2, _ = extract_batch(eng, labels, planes, multi_tree, multi=True, table=table)
+            else:
+                main.wait_stream(step.side)
+                m2.record_stream(main)
             out.append(m2)
         # rows -> pinned host memory on a side stream: the download of step k overlaps the start of step k+1
         pending = eng.to_host_async(tuple(out), slot=step.parity)
@@ -434,6 +446,7 @@ def main():
         return pending, table, model.last_counts
 
     step.parity = 0
+    step.side = torch.cuda.Stream() if os.environ.get("ALIBY_MULTI_STREAM", "1") != "0" else None
 
     # ---- experiment (--overlap): the step cut in two phases on two streams ------------------------------------------
     post_stream = torch.cuda.Stream() if args.overlap else None

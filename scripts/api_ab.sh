@@ -27,6 +27,7 @@ for t in "$@"; do
     nodefer) run nodefer ALIBY_DEFER_SUBMITS=0 ;;
     w20) run w20 ALIBY_WRITERS=20 ;;
     nofiles) run nofiles ALIBY_ABLATE=files ;;
+    nomulti) run nomulti ALIBY_MULTI_STREAM=0 ;;
     autogc) run autogc ALIBY_MANAGE_GC=0 ;;
     sw1) run sw1 ALIBY_SWITCH_INTERVAL=1e-3 ;;
     trace) run trace ALIBY_RUNNER_TRACE=1

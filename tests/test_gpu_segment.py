@@ -388,3 +388,61 @@ def test_network_last_block_as_pair_with_head_matches_the_two_launches(engine):
     model.fused.pair_head = False
     want = model.run_network(img)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+def test_dynamics_do_not_depend_on_what_the_workspace_held(engine):
+    """The dynamics initialise their per-label words and seed map where they use them instead of clearing 30 bytes per padded
+    pixel (csrc/dynamics.hip); the workspace is reused from call to call with another batch size = another layout.  Whatever
+    it held before — zeros, ones, a previous batch's words — the labels are the same."""
+    import torch
+    from aliby_amd.segment import dynamics
+
+    tiles = [_flows((224, 256), 14, 40 + k, "nuclei") for k in range(3)]
+    dP = torch.from_numpy(np.stack([t[1] for t in tiles])).cuda()
+    prob = torch.from_numpy(np.stack([t[2] for t in tiles])).cuda()
+    ref, n_ref = dynamics.masks_from_flows(engine, dP, prob)
+    ref = ref.cpu().numpy()
+    (ws,) = [w for w in dynamics._workspaces.values()]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for fill in (0x00, 0xFF, 0x7F, 0x01, "random"):
+        if fill == "random":
+            ws.copy_(torch.randint(0, 256, (ws.numel(),), dtype=torch.uint8, device="cuda", generator=g))
+        else:
+            ws.fill_(fill)
+        for sl in (slice(0, 3), slice(2, 3), slice(0, 1)):  # other batch sizes lay the same buffer out differently
+            got, n = dynamics.masks_from_flows(engine, dP[sl].contiguous(), prob[sl].contiguous())
+            assert np.array_equal(n, n_ref[sl]), (fill, sl)
+            assert np.array_equal(got.cpu().numpy(), ref[sl]), (fill, sl)
+
+
+@pytest.mark.gpu
+def test_dynamics_do_not_depend_on_the_order_of_the_foreground_list(engine, monkeypatch):
+    """The foreground pixels are compacted in 4096-pixel chunks whose order in the list is the order their workgroups reserved
+    space — usually ascending, not always.  Round 3 shipped a first-position reduction that assumed ascending positions inside a
+    run of one label: where a wave of the list straddled two chunks that had landed the other way round, inside a mask spanning
+    both, the mask's first position came out too large and two masks swapped their numbers (about once in ten runs of a
+    7-position job).  ALIBY_DEBUG_FG_REVERSE=1 makes the chunks land in DESCENDING order every time; the frame below has a mask
+    across the first chunk boundary (rows 15 | 16 of a 256-pixel-wide frame) and a small one beside its upper part."""
+    import torch
+    from aliby_amd.segment.dynamics import masks_from_flows
+    from oracle import cellpose_restated as cr
+
+    yy, xx = np.mgrid[0:64, 0:256]
+    frames = []
+    for k in range(6):  # (the critical stretch must not contain a wave boundary of the list: a few sizes, one of them will do)
+        gt = np.zeros((64, 256), np.int32)
+        gt[(yy - 16) ** 2 + (xx - 40) ** 2 <= (8 + 0.5 * k) ** 2] = 1
+        gt[(yy - 13) ** 2 + (xx - 150) ** 2 <= 3.2 ** 2] = 2
+        frames.append((gt,) + synth.analytic_flows(gt))
+    dP = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    prob = torch.from_numpy(np.stack([f[2] for f in frames])).cuda()
+    monkeypatch.delenv("ALIBY_DEBUG_FG_REVERSE", raising=False)
+    ref, n_ref = masks_from_flows(engine, dP, prob)
+    monkeypatch.setenv("ALIBY_DEBUG_FG_REVERSE", "1")
+    got, n = masks_from_flows(engine, dP, prob)
+    assert list(n_ref) == [2] * 6 and np.array_equal(n, n_ref)
+    for k, (gt, d, p) in enumerate(frames):
+        want = cr.compute_masks(d, p)
+        assert np.array_equal(ref[k].cpu().numpy(), want), k
+        assert np.array_equal(got[k].cpu().numpy(), want), (k, "reversed list")
