@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 
 import numpy as np
@@ -211,7 +212,7 @@ def check(rc: int) -> None:
 
 
 class Context:
-    """Owns an aliby_ctx*; one per process/GPU (one process per GPU, SURVEY §8b "Threading")."""
+    """Owns an aliby_ctx*; one per (thread, GPU): see default_context (one process per GPU, SURVEY §8b "Threading")."""
 
     def __init__(self, device: int = 0):
         lib = load()
@@ -239,14 +240,20 @@ class Context:
             pass
 
 
-_default_ctx: dict[int, Context] = {}
+_tls = threading.local()
 
 
 def default_context(device: int | None = None) -> Context:
+    """The calling THREAD's context for `device`.  A context owns a scratch block that several entry points use for a few
+    words each (tile rectangles of the stager, per-frame offsets of the object table and the dynamics' flow QC): the
+    position-batched runner stages the next batch on an ingest thread while the launch thread is inside the dynamics, and with
+    one context per device the stager's rectangles could land on the offsets a queued kernel was about to read.  One context
+    per (thread, device); it goes away with its thread."""
     if device is None:
         import torch
 
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+    have = _tls.__dict__.setdefault("ctx", {})
+    if device not in have:
+        have[device] = Context(device)
+    return have[device]

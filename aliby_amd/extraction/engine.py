@@ -126,13 +126,18 @@ class FeatureEngine:
     def _profile(self):
         return self.profile if self.profile is not None else FeatureEngine.shared_profile
 
+    @property
+    def ctx(self):
+        """The context of the thread that is calling (aliby_amd/_lib.py default_context): an engine built on one thread and
+        used on another — the runner's tilers are — never shares a scratch block with a call in flight elsewhere."""
+        return _lib.default_context(self.device)
+
     def __init__(self, device: int | None = None):
         if not torch.cuda.is_available():
             raise _lib.AlibyHipError("no GPU visible: the HIP feature engine has no CPU fallback")
         if device is None:
             device = torch.cuda.current_device()
         self.device = device
-        self.ctx = _lib.default_context(device)
         self.lib = self.ctx.lib
         self.profile = None  # set to {} to time kernel groups with HIP events on the launch stream
         self.profile_sample = {}  # group name -> n: bracket only every n-th launch of that group

@@ -77,6 +77,11 @@ _POOL_SHAPES = {(32, 32, False), (32, 64, False), (64, 64, False), (64, 128, Fal
 
 
 class FusedUNet:
+    @property
+    def h(self):
+        """Context handle of the calling thread (contexts are per thread: aliby_amd/_lib.py default_context)."""
+        return self.eng.ctx.handle
+
     def __init__(self, net, eng, dtype=torch.bfloat16, mfma_levels=(0, 1, 2, 3)):
         assert dtype == torch.bfloat16, "the fused kernels are bf16"
         self.eng, self.dtype = eng, dtype
@@ -91,7 +96,7 @@ class FusedUNet:
         self.deep_kernel = os.environ.get("ALIBY_CONV_DEEP", "1") != "0"
         self.conv_stats = {}  # timing group -> [algorithmic bytes, flops] of the MFMA conv launches bracketed with events
         # every call made through self.lib is an asynchronous kernel launch: they keep the interpreter lock (see _lib.load_fast)
-        self.lib, self.h = (_lib.load_fast() if os.environ.get("ALIBY_FAST_LAUNCH", "1") != "0" else eng.lib), eng.ctx.handle
+        self.lib = _lib.load_fast() if os.environ.get("ALIBY_FAST_LAUNCH", "1") != "0" else eng.lib
         net = net.float().eval()
         self.down = []
         for i, blk in enumerate(net.down):
