@@ -4,7 +4,7 @@ How many host cores this process may use.
 A GPU box hands each GPU process a share of the host (16 cores per GPU on the MI355X pool) while `os.cpu_count()` reports
 every core of the machine: worker pools sized by `os.cpu_count()` oversubscribe the share by an order of magnitude (a fork
 pool of 256 NumPy workers ran 50x slower per task than 16).  Order of precedence: ALIBY_HOST_CORES, the cgroup CPU quota,
-the affinity mask capped at 16 per rank.
+the affinity mask capped at 16 per rank; quota and mask are divided by LOCAL_WORLD_SIZE (the ranks of a node share them).
 """
 
 from __future__ import annotations
@@ -34,10 +34,15 @@ def usable_cores(default_cap: int = 16) -> int:
     if env:
         return max(1, int(env))
     affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # ranks of one node (torch.distributed.run sets LOCAL_WORLD_SIZE) share the node's quota / affinity mask
+    try:
+        local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    except ValueError:
+        local = 1
     quota = _cgroup_quota()
     if quota is not None:
-        return max(1, min(affinity, int(quota + 0.5)))
-    return max(1, min(affinity, default_cap))
+        return max(1, min(affinity, int(quota + 0.5)) // local)
+    return max(1, min(affinity // local, default_cap))
 
 
 def describe() -> dict:
