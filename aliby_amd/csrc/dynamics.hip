@@ -773,7 +773,12 @@ int aliby_masks_from_flows(aliby_ctx* ctx, const float* dP, const float* cellpro
       q.gscratch = nullptr;
       if (need > 32 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_diffuse<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
-      hipLaunchKernelGGL((k_diffuse<false>), dim3(n_obj), dim3(aliby_pick_block((long long)max_h * max_w)), need, s, q);
+      // four waves per mask whatever its size: a sweep is a few dozen instructions per pixel behind one barrier, and one wave
+      // walking 10+ rows per lane per sweep (the per-object default for small windows) left the SIMDs idle 70 % of the time —
+      // 2.66 -> 1.8 ms for 16 k nuclei (ALIBY_DIFFUSE_BLOCK: 64 / 128 / 256 = 5.5 / 4.8 / 4.6 ms for the whole dynamics)
+      const char* db = getenv("ALIBY_DIFFUSE_BLOCK");
+      const int dblock = db && atoi(db) >= 64 && atoi(db) <= 256 ? (atoi(db) & ~63) : 256;
+      hipLaunchKernelGGL((k_diffuse<false>), dim3(n_obj), dim3(dblock), need, s, q);
     } else {
       // ctx scratch holds the offsets in its first bytes: put the slabs after them
       const int g = n_obj < 256 ? n_obj : 256;
