@@ -1066,4 +1066,24 @@ def cpu_baseline_timelapse(tl, tree, n_tp):
 
 
 if __name__ == "__main__":
-    main()
+    # stdout carries the ONE JSON line: whatever the steps print on the way (the reference's own progress messages, mirrored —
+    # "Saving ...", "Tiler:TrapIdentification: Trying again.") goes to stderr
+    import contextlib
+
+    class _JsonOnly:
+        def __init__(self, out, err):
+            self.out, self.err = out, err
+
+        def write(self, text):
+            (self.out if text.lstrip().startswith('{"metric"') or (text == "\n" and self._json) else self.err).write(text)
+            self._json = text.lstrip().startswith('{"metric"')
+            return len(text)
+
+        _json = False
+
+        def flush(self):
+            self.out.flush()
+            self.err.flush()
+
+    with contextlib.redirect_stdout(_JsonOnly(sys.stdout, sys.stderr)):
+        main()
