@@ -441,3 +441,55 @@ def test_run_positions_mixed_save_and_host_only_steps(tmp_path, engine):
                 da, db = za["arr_0"].item(), zb["arr_0"].item()
                 assert sorted(da) == sorted(db) == ["drift", "pixels"] and np.array_equal(da["pixels"], db["pixels"])
                 assert _same(da["drift"], db["drift"])
+
+
+def test_run_positions_with_an_empty_position_and_a_large_object(tmp_path, engine):
+    """Batches whose frames are not alike: one position without any object (its count is 0 in the object table the runner
+    builds from the segmenter's counts), one with an object wider than the LDS-resident window (the per-object kernels take
+    their global-scratch variants, and neither the family fan-out nor the side-by-side colocalisation launch is taken), among
+    ordinary ones — against single calls, table for table."""
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    shape = (224, 256)
+    fovs = [synth.make_fov(2, 60 + i, shape=shape, n_channels=2, n_target=8) for i in range(4)]
+    rng = np.random.default_rng(9)
+    empty = dict(pixels=rng.integers(90, 140, (2, 1, *shape)).astype(np.uint16), nuclei=np.zeros(shape, np.uint16))
+    yy, xx = np.mgrid[0 : shape[0], 0 : shape[1]]
+    big_lab = ((yy - 110) ** 2 + (xx - 128) ** 2 <= 50**2).astype(np.uint16)
+    big = dict(pixels=(rng.integers(90, 140, (2, 1, *shape)) + 400 * big_lab).astype(np.uint16), nuclei=big_lab)
+
+    def run(order, batch_size, out):
+        override = _keyed_override(order)
+
+        def pipes():  # (a pipeline dict is consumed by its run: init_step pops image_kwargs, as the reference does)
+            made = []
+            for f in order:
+                p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1],
+                                         features_to_extract=("sizeshape", "intensity", "texture", "radial_distribution", "zernike"))
+                p["steps"]["tile"]["image_kwargs"] = {"source": f["pixels"][None]}
+                p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+                made.append(p)
+            return made
+
+        names = [f"Q{i:02d}__1" for i in range(len(order))]
+        single = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=out / "single")[0] for p, nm in zip(pipes(), names)]
+        got = run_positions(pipes(), names, out / "batched", batch_size=batch_size)
+        return single, [g[0] for g in got]
+
+    for k, (order, bs) in enumerate((([fovs[0], empty, fovs[1]], 3), ([fovs[2], big, fovs[3], empty], 4), ([empty], 1))):
+        single, got = run(order, bs, tmp_path / f"case{k}")
+        for i, (a, b) in enumerate(zip(got, single)):
+            assert a.schema.equals(b.schema) and a.num_rows == b.num_rows, (k, i, a.num_rows, b.num_rows)
+            for c in a.column_names:
+                x, y = a[c].to_numpy(zero_copy_only=False), b[c].to_numpy(zero_copy_only=False)
+                if k == 1 and x.dtype.kind == "f":
+                    # the large object of this batch selects 256-thread workgroups (and global scratch) for every object of
+                    # the batch; alone, the ordinary positions run with one wave per object: the floating-point reductions
+                    # (second moments, Haralick sums) then add in another order — last bits, not values
+                    scale = float(np.nanmax(np.abs(y))) if y.size and np.isfinite(y).any() else 0.0  # (central moments cancel to ~0)
+                    assert np.allclose(x, y, rtol=1e-9, atol=1e-12 + 1e-9 * scale, equal_nan=True), (k, i, c)
+                else:
+                    assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (k, i, c)
+    assert any(g.num_rows == 0 for g in got)
