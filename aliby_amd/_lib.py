@@ -85,6 +85,8 @@ _SIGNATURES = {
     "aliby_nn_fused_act_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "aliby_nn_conv3x3_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "aliby_nn_conv3x3_deep_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "aliby_nn_conv3x3_deep16_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "aliby_nn_pack_conv3x3_deep16_bf16": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "aliby_nn_maxpool2_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "aliby_debug_conv_deep_trace": (_i, [_vp, _vp]),
     "aliby_track_stitch": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp]),

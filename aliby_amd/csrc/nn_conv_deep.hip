@@ -342,6 +342,254 @@ int launch_deep(DeepArgs& a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same unit on v_mfma_f32_16x16x32_bf16 (round 3).  Under a dense MFMA stream the chip holds a higher clock on this shape
+// than on 32x32x16 (MI355X_MICROARCH.md "Clocks under load" item 7; timing-only check in this kernel: +4.5 %), at the same
+// cycles per FLOP and the same operand traffic.  What changes against k_conv3x3_deep:
+//   * a wave's 32 output channels x 224 positions are 2 x 14 tiles of 16 x 16; a k-step is 32 channels: per (tap, k-step) two
+//     weight fragments (channel halves a = 0, 1) and, per block of 32 positions, two pixel fragments (position halves h): each
+//     pixel fragment feeds two MFMAs, each weight fragment fourteen;
+//   * fragment layout (A[row l & 15][k = 8 (l >> 4) + j], B[k][col l & 15]): lane l reads the octet plane of ITS k-group, so a
+//     ds_read_b128 touches four planes.  Its four 16-lane service groups pair k-groups (0, 1) and (2, 3): the two planes of a
+//     pair must sit a multiple of 16 slots apart for the group to cover all 64 banks once.  With a plane pitch = 4 mod 16 that
+//     holds for planes p and p + 4, so k-step jj of a 64-channel slice takes the octets (jj*2, jj*2 + 4, jj*2 + 1, jj*2 + 5) as
+//     its k-groups 0..3 — the packed weights follow (k_pack_deep16).  The staging writes (8 octets of one position per 8 lanes)
+//     are 2-way conflicted with this pitch instead of conflict-free: 11 writes per thread and slice against 252 reads;
+//   * output rows: row 4 g + i of channel half a is output channel 8 g + 4 a + i of the wave's 32, so a lane (position c, row
+//     group g) holds 8 CONTIGUOUS channels of each of its positions: one 16-byte store / residual load per position.
+// Another summation order than the 32x32x16 kernel (32 channels per instruction): the two kernels agree to fp32 rounding, not
+// bit for bit; exact on integer data (tests/test_gpu_conv.py).
+// MEASURED SLOWER than k_conv3x3_deep (5.71 against 4.75 ms per forward; DESIGN.md 3.2: the 2-way write conflicts this pitch
+// costs the staging phase, and 124-156 bytes of scratch per lane at 128 / 256 input channels): kept behind the C ABI
+// (aliby_nn_conv3x3_deep16_bf16) with its tests, not used by the network.
+constexpr int DC_PLANE16 = ((DC_WIN_MAX + 15 - 4) / 16) * 16 + 4 >= DC_WIN_MAX ? ((DC_WIN_MAX + 15 - 4) / 16) * 16 + 4 : ((DC_WIN_MAX + 15 - 4) / 16) * 16 + 20;
+static_assert(DC_PLANE16 % 16 == 4 && DC_PLANE16 >= DC_WIN_MAX, "plane pitch of the 16x16x32 kernel");
+constexpr int DC16_LDS_BYTES = 8 * DC_PLANE16 * 16 + DC_ITERS * 256 * 4;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CIN, bool UP>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_deep16(DeepArgs a) {
+  constexpr int S = CIN / 64, K32T = CIN / 32;  // K slices, 32-channel k-steps in the packed array
+  extern __shared__ uint4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6;
+  const int c16 = lane & 15, kg = lane >> 4;  // MFMA role: column (position) / k-group = output row group
+  const int pl = tid & 7, pos0 = tid >> 3;    // staging role: a fixed channel octet of position pos0 + 32 * round
+  const int IH = UP ? a.H >> 1 : a.H, IW = UP ? a.W >> 1 : a.W;
+  const int LW = a.LW, HP = a.HP;
+  const int WIN = DC_RUN + 2 * LW + 2;
+  const int cs = CIN / 8;
+  int* const goff = reinterpret_cast<int*>(lds + 8 * DC_PLANE16) + tid;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int per_xcd = (a.ntiles + 7) >> 3;
+  const int t_end = min(a.ntiles, (xcd + 1) * per_xcd);
+
+  for (int tile = xcd * per_xcd + slot; tile < t_end; tile += nslots) {
+    const int half = tile % a.nhalf, run = tile / a.nhalf;
+    const int q0 = a.q_begin + run * DC_RUN;
+    const int p_first = q0 - LW - 1;
+    unsigned inside = 0, later = 0;
+    const int n0 = max(0, ((p_first / LW) - 1) / HP);
+    {
+      const int P0 = p_first + pos0;
+      int r = P0 >= 0 ? P0 / LW : -1, c = P0 - r * LW;
+      int n = r >= 1 ? (r - 1) / HP : 0, y = r >= 1 ? (r - 1) - n * HP : r - 1;
+#pragma unroll
+      for (int it = 0; it < DC_ITERS; ++it) {
+        const bool ok = y >= 0 && y < a.H && c >= 1 && c <= a.W && n < a.N;
+        inside |= (unsigned)ok << it;
+        later |= (unsigned)(n > n0) << it;
+        const int nn = min(n, a.N - 1), yy = min(max(y, 0), a.H - 1), xx = min(max(c - 1, 0), a.W - 1);
+        goff[it * 256] = ((nn * IH + (UP ? yy >> 1 : yy)) * IW + (UP ? xx >> 1 : xx)) * cs + pl;
+        c += 32;
+        while (c >= LW) {
+          c -= LW;
+          if (++y == HP) { y = 0; ++n; }
+        }
+      }
+    }
+    const int n1 = min(n0 + 1, a.N - 1);
+    uint4 v[DC_ITERS];
+    auto request = [&](int s) {
+      const uint4* inS = a.in + s * 8;
+#pragma unroll
+      for (int it = 0; it < DC_ITERS; ++it) v[it] = inS[(unsigned)goff[it * 256]];
+    };
+    request(0);
+
+    // ---- accumulators start at bias + residual; lane (c16, kg) holds channels c0 .. c0 + 7 of positions q0 + 32 b + 16 h + c16
+    const int c0 = half * 128 + cb * 32 + kg * 8;
+    const int ocs = a.COUT / 8;
+    f32x4_t acc[DC_NB][2][2];  // [block][channel half a][position half h]
+    int qbase = q0 + c16;  // (re-read through an empty asm before the epilogue: its 14 positions are then computed again there
+    // instead of being kept in 40 registers across the MFMA loops, which is what common-subexpression elimination does otherwise)
+    auto where = [&](int b, int h, int& n, int& y, int& x) {  // image, row, column of this lane's position (b, h)
+      const int q = qbase + b * 32 + h * 16;
+      const int r = q / LW;  // >= 1: q >= q_begin = LW
+      x = q - r * LW - 1;
+      n = (r - 1) / HP;
+      y = (r - 1) - n * HP;
+    };
+    {
+      float b8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) b8[k] = a.bias ? a.bias[c0 + k] : 0.f;
+      if (a.res) {
+        const int RH = a.H >> a.res_up, RW = a.W >> a.res_up;
+        uint4 rr[DC_NB][2];
+#pragma unroll
+        for (int b = 0; b < DC_NB; ++b)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int n, y, x;
+            where(b, h, n, y, x);
+            const int nn = min(n, a.N - 1), yy = min(y, a.H - 1), xx = min(max(x, 0), a.W - 1);  // (clamped: not every position is stored)
+            rr[b][h] = a.res[(unsigned)(((nn * RH + (yy >> a.res_up)) * RW + (xx >> a.res_up)) * ocs + (c0 >> 3))];
+          }
+#pragma unroll
+        for (int b = 0; b < DC_NB; ++b)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const unsigned rw[4] = {rr[b][h].x, rr[b][h].y, rr[b][h].z, rr[b][h].w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[b][0][h][2 * j] = b8[2 * j] + dc_bf2f(rw[j] & 0xffffu);
+              acc[b][0][h][2 * j + 1] = b8[2 * j + 1] + dc_bf2f(rw[j] >> 16);
+              acc[b][1][h][2 * j] = b8[4 + 2 * j] + dc_bf2f(rw[2 + j] & 0xffffu);
+              acc[b][1][h][2 * j + 1] = b8[4 + 2 * j + 1] + dc_bf2f(rw[2 + j] >> 16);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int b = 0; b < DC_NB; ++b)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[b][0][h][k] = b8[k]; acc[b][1][h][k] = b8[4 + k]; }
+      }
+    }
+    // packed weights: [cout block][tap][32-channel k-step][a][lane][8]
+    const bf16x8_t* wbase = reinterpret_cast<const bf16x8_t*>(a.wpk) + (size_t)(half * 4 + cb) * 9 * K32T * 2 * 64 + lane;
+
+    for (int s = 0; s < S; ++s) {
+      const bf16x8_t* wp = wbase + (size_t)(2 * s) * 2 * 64;  // fragment (tap, jj, a) of this slice at wp[((tap * K32T + jj) * 2 + a) * 64]
+      constexpr int NW = 18;  // weight steps per slice, in (jj, tap) order; two fragments each
+      constexpr int WD = 2;  // weight steps in flight: a step is 28 MFMAs = 448 cycles, the cover two 7-MFMA steps give the 32x32x16 kernel
+      bf16x8_t wring[WD][2];
+      auto wfrag = [&](int i, int aa) { return wp[(((i % 9) * K32T + (i / 9)) * 2 + aa) * 64]; };
+#pragma unroll
+      for (int i = 0; i < WD - 1; ++i) { wring[i][0] = wfrag(i, 0); wring[i][1] = wfrag(i, 1); }
+      f32x2_t sc[4], sh[4], sh1[4];
+      {
+        const int ch = s * 64 + pl * 8;
+        const float* sp0 = a.shift + (size_t)n0 * a.shift_stride + ch;
+        const float* sp1 = a.shift + (size_t)n1 * a.shift_stride + ch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sc[k] = f32x2_t{a.scale[ch + 2 * k], a.scale[ch + 2 * k + 1]};
+          sh[k] = f32x2_t{sp0[2 * k], sp0[2 * k + 1]};
+          sh1[k] = f32x2_t{sp1[2 * k], sp1[2 * k + 1]};
+        }
+      }
+      __syncthreads();  // every wave is done reading the previous slice's planes
+#pragma unroll
+      for (int it = 0; it < DC_ITERS; ++it) {
+        f32x2_t shs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) shs[k] = ((later >> it) & 1u) ? sh1[k] : sh[k];
+        const uint4 o = dc_act8(v[it], sc, shs, 0u - ((inside >> it) & 1u));
+        const int wp_ = pos0 + 32 * it;
+        if (wp_ < WIN) lds[pl * DC_PLANE16 + wp_] = o;
+      }
+      __syncthreads();
+
+      // k-group kg of k-step jj reads octet plane 2 jj + (kg >> 1) + 4 (kg & 1) (see the header comment)
+      const bf16x8_t* L = reinterpret_cast<const bf16x8_t*>(lds) + ((kg >> 1) + 4 * (kg & 1)) * DC_PLANE16 + c16;
+      const int row_off[3] = {0, LW, 2 * LW};
+      constexpr int NPF = 2 * DC_NB;     // pixel fragments per weight step
+      constexpr int NF = NW * NPF;       // pixel fragments per slice (two MFMAs each)
+      constexpr int PD = 3;  // pixel fragments in flight (two MFMAs each)
+      bf16x8_t pring[PD];
+      auto pfrag = [&](int f) {
+        const int i = f / NPF, bh = f % NPF, jj = i / 9, tap = i % 9;
+        return L[2 * jj * DC_PLANE16 + (bh >> 1) * 32 + (bh & 1) * 16 + row_off[tap / 3] + tap % 3];
+      };
+#pragma unroll
+      for (int f = 0; f < PD - 1; ++f) pring[f] = pfrag(f);
+      sfor<NW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i == NW - 5) {  // request the next slice's window (as DC_REQ_AT = 27 of 36 in the 32x32x16 kernel)
+          if (s + 1 < S) request(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (i + WD - 1 < NW) {
+          wring[(i + WD - 1) % WD][0] = wfrag(i + WD - 1, 0);
+          wring[(i + WD - 1) % WD][1] = wfrag(i + WD - 1, 1);
+        }
+        sfor<NPF>([&](auto bc) {
+          constexpr int bh = decltype(bc)::value, f = i * NPF + bh, b = bh >> 1, h = bh & 1;
+          if constexpr (f + PD - 1 < NF) pring[(f + PD - 1) % PD] = pfrag(f + PD - 1);
+          acc[b][0][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wring[i % WD][0], pring[f % PD], acc[b][0][h], 0, 0, 0);
+          acc[b][1][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wring[i % WD][1], pring[f % PD], acc[b][1][h], 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+
+    // ---- epilogue: fp32 -> bf16, 16 contiguous bytes (8 channels) per lane and position
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(qbase));
+#pragma unroll
+    for (int b = 0; b < DC_NB; ++b)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int n, y, x;
+        where(b, h, n, y, x);
+        const bool ok = q0 + b * 32 + h * 16 + c16 < a.q_end && y < a.H && x >= 0 && x < a.W && n < a.N;
+        if (ok)
+          a.out[(unsigned)(((n * a.H + y) * a.W + x) * ocs + (c0 >> 3))] =
+              make_uint4(dc_pack2(acc[b][0][h][0], acc[b][0][h][1]), dc_pack2(acc[b][0][h][2], acc[b][0][h][3]),
+                         dc_pack2(acc[b][1][h][0], acc[b][1][h][1]), dc_pack2(acc[b][1][h][2], acc[b][1][h][3]));
+      }
+  }
+}
+
+template <int CIN, bool UP>
+int launch_deep16(DeepArgs& a, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_deep16<CIN, UP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DC16_LDS_BYTES));
+    attr_done = true;
+  }
+  const int per_xcd = (a.ntiles + 7) / 8;
+  const int nslots = per_xcd < 64 ? per_xcd : 64;  // 2 workgroups per CU, 32 CUs per XCD
+  hipLaunchKernelGGL((k_conv3x3_deep16<CIN, UP>), dim3(8 * nslots), dim3(256), DC16_LDS_BYTES, stream, a);
+  KERNEL_CHECK();
+  return ALIBY_OK;
+}
+
+// weights for k_conv3x3_deep16: out[(((cb * 9 + tap) * (CIN / 32) + k32) * 2 + a) * 64 + lane][j] =
+// W[32 cb + 8 (r >> 2) + 4 a + (r & 3)][64 (k32 >> 1) + 8 oct + j][tap], r = lane & 15, kg = lane >> 4,
+// oct = 2 (k32 & 1) + (kg >> 1) + 4 (kg & 1)
+__global__ void k_pack_deep16(const float* __restrict__ w, int cout, int cin, unsigned short* __restrict__ out, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  size_t rest = i >> 9;
+  const int aa = (int)(rest & 1);
+  rest >>= 1;
+  const int k32n = cin / 32;
+  const int k32 = (int)(rest % k32n);
+  rest /= k32n;
+  const int tap = (int)(rest % 9), cb = (int)(rest / 9);
+  const int r = lane & 15, kg = lane >> 4;
+  const int co = cb * 32 + 8 * (r >> 2) + 4 * aa + (r & 3);
+  const int ci = 64 * (k32 >> 1) + 8 * (2 * (k32 & 1) + (kg >> 1) + 4 * (kg & 1)) + j;
+  const float v = w[((size_t)co * cin + ci) * 9 + tap];
+  out[i] = (unsigned short)(dc_pack2(v, 0.f) & 0xffffu);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Loader-specialised form of the same unit (round 3).  Phase elimination on k_conv3x3_deep (scripts/deep_phases.sh, timing only):
 // without the window loads 256 -> 256 runs 24 % faster, without residual loads 9 %, without stores 9 %, without all three
 // 31 % (1458 TFLOP/s) — although the loads are issued a k-step ahead, and moving the request anywhere in the slice changes
@@ -626,9 +874,9 @@ extern "C" int aliby_debug_conv_deep_trace(aliby_ctx* ctx, void* stamps_dev) {
   return ALIBY_OK;
 }
 
-extern "C" int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
-                                          const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
-                                          int N, int H, int W, int CIN, int COUT, int in_up, void* stream_) {
+static int deep_entry(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale, const float* shift,
+                      int shift_per_sample, const float* bias, const void* res, int res_up, int N, int H, int W, int CIN, int COUT,
+                      int in_up, void* stream_, bool m16) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   ARG_CHECK(ctx && in && wpk && out && scale && shift, "conv3x3_deep: null argument");
   ARG_CHECK(N > 0 && H > 0 && W > 0, "conv3x3_deep: empty shape");
@@ -667,6 +915,11 @@ extern "C" int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const 
   static const int stagger = [] { const char* e = getenv("ALIBY_DEEP_STAGGER"); return e ? atoi(e) : 0; }();
   a.stagger = stagger;
   a.trace = g_deep_trace;
+  if (m16) {
+    if (CIN == 64) return in_up ? launch_deep16<64, true>(a, stream) : launch_deep16<64, false>(a, stream);
+    if (CIN == 128) return in_up ? launch_deep16<128, true>(a, stream) : launch_deep16<128, false>(a, stream);
+    return in_up ? launch_deep16<256, true>(a, stream) : launch_deep16<256, false>(a, stream);
+  }
   const char* ls = getenv("ALIBY_DEEP_LS");  // loader-specialised form: measured slower, kept for A/B; read per call
   if (ls && atoi(ls)) {
     if (CIN == 64) return in_up ? launch_deep_ls<64, true>(a, stream) : launch_deep_ls<64, false>(a, stream);
@@ -676,6 +929,28 @@ extern "C" int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const 
   if (CIN == 64) return in_up ? launch_deep<64, true>(a, stream) : launch_deep<64, false>(a, stream);
   if (CIN == 128) return in_up ? launch_deep<128, true>(a, stream) : launch_deep<128, false>(a, stream);
   return in_up ? launch_deep<256, true>(a, stream) : launch_deep<256, false>(a, stream);
+}
+
+extern "C" int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
+                                          const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
+                                          int N, int H, int W, int CIN, int COUT, int in_up, void* stream_) {
+  return deep_entry(ctx, in, wpk, out, scale, shift, shift_per_sample, bias, res, res_up, N, H, W, CIN, COUT, in_up, stream_, false);
+}
+
+extern "C" int aliby_nn_conv3x3_deep16_bf16(aliby_ctx* ctx, const void* in, const void* wpk16, void* out, const float* scale,
+                                            const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
+                                            int N, int H, int W, int CIN, int COUT, int in_up, void* stream_) {
+  return deep_entry(ctx, in, wpk16, out, scale, shift, shift_per_sample, bias, res, res_up, N, H, W, CIN, COUT, in_up, stream_, true);
+}
+
+extern "C" int aliby_nn_pack_conv3x3_deep16_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN, void* wpk16, void* stream_) {
+  ARG_CHECK(ctx && w_oihw && wpk16, "pack_conv_deep16: null argument");
+  ARG_CHECK(COUT > 0 && COUT % 32 == 0 && CIN > 0 && CIN % 64 == 0, "pack_conv_deep16: COUT must be a multiple of 32 and CIN of 64");
+  const size_t total = (size_t)COUT * CIN * 9;
+  hipLaunchKernelGGL(k_pack_deep16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), w_oihw, COUT, CIN,
+                     static_cast<unsigned short*>(wpk16), total);
+  KERNEL_CHECK();
+  return ALIBY_OK;
 }
 
 extern "C" int aliby_nn_maxpool2_bf16(aliby_ctx* ctx, const void* in, void* out, int N, int H, int W, int C, void* stream_) {

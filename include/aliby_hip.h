@@ -197,6 +197,15 @@ int aliby_track_stitch(aliby_ctx* ctx, const uint16_t* prev, const uint16_t* cur
 int aliby_nn_conv3x3_deep_bf16(aliby_ctx* ctx, const void* in, const void* wpk, void* out, const float* scale,
                                const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
                                int N, int H, int W, int CIN, int COUT, int in_up, void* stream);
+
+/* The same unit on v_mfma_f32_16x16x32_bf16 (the shape the chip holds a higher clock on: nn_conv_deep.hip).  Same arguments and
+ * meaning; `wpk16` is packed by aliby_nn_pack_conv3x3_deep16_bf16 (w_oihw float32 [COUT, CIN, 3, 3], COUT a multiple of 32, CIN
+ * of 64 -> COUT * CIN * 9 bf16).  Accumulates 32 input channels per instruction: agrees with aliby_nn_conv3x3_deep_bf16 to fp32
+ * rounding, not bit for bit. */
+int aliby_nn_conv3x3_deep16_bf16(aliby_ctx* ctx, const void* in, const void* wpk16, void* out, const float* scale,
+                               const float* shift, int shift_per_sample, const float* bias, const void* res, int res_up,
+                               int N, int H, int W, int CIN, int COUT, int in_up, void* stream);
+int aliby_nn_pack_conv3x3_deep16_bf16(aliby_ctx* ctx, const float* w_oihw, int COUT, int CIN, void* wpk16, void* stream);
 /* Diagnostics for the deep kernel: stamps_dev [8 tiles][32] uint64 shader-clock stamps of wave 0 of workgroup 0 (0 tile start,
  * 1 set-up done, then per K slice s: 2+4s after the first barrier, 3+4s prologue written, 4+4s after the second barrier,
  * 5+4s MFMA loop done; 2+4S epilogue done).  NULL switches it off (the default). */

@@ -1,5 +1,5 @@
 """Microbenchmark of the deep-level K-loop convolution (csrc/nn_conv_deep.hip) at the network's shapes (run on the GPU box).
-usage: python scripts/bench_conv_deep.py [N=288]"""
+usage: python scripts/bench_conv_deep.py [N=288] [m16]      (m16: the v_mfma_f32_16x16x32_bf16 form)"""
 import sys
 
 import torch
@@ -10,6 +10,7 @@ from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr  # noqa
 
 eng = FeatureEngine()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 288
+M16 = len(sys.argv) > 2 and sys.argv[2] == "m16"
 tot_ms = tot_fl = 0.0
 # (cin, cout, upsampled input, H, how many times the network runs this shape per forward)
 for cin, cout, up, H, count in [(64, 128, 0, 56, 1), (128, 128, 0, 56, 6), (256, 128, 1, 56, 1), (128, 256, 0, 28, 1), (256, 256, 0, 28, 7)]:
@@ -17,7 +18,10 @@ for cin, cout, up, H, count in [(64, 128, 0, 56, 1), (128, 128, 0, 56, 6), (256,
     x = torch.randn(N, ih, ih, cin, device="cuda").bfloat16()
     w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
     wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
-    _lib.check(eng.lib.aliby_nn_pack_conv3x3_bf16(eng.ctx.handle, _ptr(w), cout, cin, cin, _ptr(wpk), _stream_ptr()))
+    if M16:
+        _lib.check(eng.lib.aliby_nn_pack_conv3x3_deep16_bf16(eng.ctx.handle, _ptr(w), cout, cin, _ptr(wpk), _stream_ptr()))
+    else:
+        _lib.check(eng.lib.aliby_nn_pack_conv3x3_bf16(eng.ctx.handle, _ptr(w), cout, cin, cin, _ptr(wpk), _stream_ptr()))
     scale = torch.ones(cin, device="cuda")
     shift = torch.zeros(N, cin, device="cuda")
     bias = torch.zeros(cout, device="cuda")
@@ -25,7 +29,7 @@ for cin, cout, up, H, count in [(64, 128, 0, 56, 1), (128, 128, 0, 56, 6), (256,
     out = torch.empty(N, H, H, cout, device="cuda", dtype=torch.bfloat16)
 
     def run():
-        _lib.check(eng.lib.aliby_nn_conv3x3_deep_bf16(eng.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1, _ptr(bias),
+        _lib.check((eng.lib.aliby_nn_conv3x3_deep16_bf16 if M16 else eng.lib.aliby_nn_conv3x3_deep_bf16)(eng.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1, _ptr(bias),
                                                       _ptr(res), 0, N, H, H, cin, cout, up, _stream_ptr()))
 
     for _ in range(3):

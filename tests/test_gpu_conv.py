@@ -410,7 +410,7 @@ def test_conv_unit_rejects_unsupported_shapes(engine):
 DEEP = [(64, 128, False), (128, 128, False), (128, 256, False), (256, 256, False), (256, 128, True), (128, 128, True)]
 
 
-def _run_deep(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
+def _run_deep(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W, m16=False):
     import torch
     from aliby_amd import _lib
     from aliby_amd.extraction.engine import _ptr, _stream_ptr
@@ -418,9 +418,12 @@ def _run_deep(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
     n, cin = x.shape[0], x.shape[-1]
     cout = w.shape[0]
     wpk = torch.empty(cout * cin * 9, dtype=torch.bfloat16, device="cuda")
-    _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), cout, w.shape[1], cin, _ptr(wpk), _stream_ptr()))
+    if m16:  # the 16x16x32 form: its own fragment order
+        _lib.check(engine.lib.aliby_nn_pack_conv3x3_deep16_bf16(engine.ctx.handle, _ptr(w.contiguous()), cout, cin, _ptr(wpk), _stream_ptr()))
+    else:
+        _lib.check(engine.lib.aliby_nn_pack_conv3x3_bf16(engine.ctx.handle, _ptr(w), cout, w.shape[1], cin, _ptr(wpk), _stream_ptr()))
     out = torch.full((n, H, W, cout), float("nan"), dtype=torch.bfloat16, device="cuda")
-    _lib.check(engine.lib.aliby_nn_conv3x3_deep_bf16(
+    _lib.check((engine.lib.aliby_nn_conv3x3_deep16_bf16 if m16 else engine.lib.aliby_nn_conv3x3_deep_bf16)(
         engine.ctx.handle, _ptr(x), _ptr(wpk), _ptr(out), _ptr(scale), _ptr(shift), 1 if shift.ndim == 2 else 0,
         _ptr(bias) if bias is not None else 0, _ptr(res) if res is not None else 0, 1 if res_up else 0, n, H, W, cin, cout,
         1 if in_up else 0, _stream_ptr()))
@@ -428,9 +431,10 @@ def _run_deep(engine, x, w, scale, shift, bias, res, res_up, in_up, H, W):
     return out
 
 
+@pytest.mark.parametrize("m16", [False, True], ids=["mfma32x32x16", "mfma16x16x32"])
 @pytest.mark.parametrize("shape", [(3, 28, 28), (5, 56, 56), (2, 20, 36), (1, 12, 50), (9, 28, 28)])
 @pytest.mark.parametrize("cin,cout,in_up", DEEP)
-def test_deep_conv_exact_on_integer_data(engine, cin, cout, in_up, shape):
+def test_deep_conv_exact_on_integer_data(engine, cin, cout, in_up, shape, m16):
     """aliby_nn_conv3x3_deep_bf16 (one launch, fp32 accumulation over the whole 9*CIN reduction) on data where every product and
     sum is exact: any mistake in the flattened-position / tall-image / fragment logic is a wrong integer.  Images of several
     sizes, batches that end inside a tile, per-sample shifts (a window spans two images), upsampled input and residual."""
@@ -445,12 +449,12 @@ def test_deep_conv_exact_on_integer_data(engine, cin, cout, in_up, shape):
     shift = torch.randint(-1, 2, (n, cin), generator=g).float().cuda()
     bias = torch.randint(-2, 3, (cout,), generator=g).float().cuda()
     res = torch.randint(-3, 4, (n, H // 2, W // 2, cout), generator=g).to(torch.bfloat16).cuda()
-    out = _run_deep(engine, x, w, scale, shift, bias, res, True, in_up, H, W)
+    out = _run_deep(engine, x, w, scale, shift, bias, res, True, in_up, H, W, m16=m16)
     ref = _reference(x, w, scale, shift, bias, res, True, in_up)
     assert float(ref.abs().max()) <= 256
     assert torch.equal(out.float(), ref), (out.float() - ref).abs().max()
     # no residual, shared shift, no bias
-    out2 = _run_deep(engine, x, w, scale, shift[0].contiguous(), None, None, False, in_up, H, W)
+    out2 = _run_deep(engine, x, w, scale, shift[0].contiguous(), None, None, False, in_up, H, W, m16=m16)
     assert torch.equal(out2.float(), _reference(x, w, scale, shift[0], None, None, False, in_up))
 
 
