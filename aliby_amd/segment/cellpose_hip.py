@@ -54,9 +54,16 @@ def taper_mask(by, bx, sig=7.5):
 
 
 class CellposeModel:
-    def __init__(self, gpu=True, device=None, pretrained_model=None, net=None, net_dtype="float32", seed=0,
+    def __init__(self, gpu=True, device=None, pretrained_model=None, net=None, net_dtype=None, seed=0,
                  flows_override=None, run_network_with_override=False, bsize=224, tile_overlap=0.1, batch_size=64,
-                 **ignored):
+                 use_bfloat16=True, **ignored):
+        """net_dtype: "bfloat16" (the default) runs the network on the hand-written MFMA kernels (segment/fused_unet.py); "float32" /
+        "float16" run the same module through PyTorch's own convolutions (MIOpen: a numerical reference, tens of seconds of kernel
+        search at the first batch, several times slower).  `use_bfloat16` is cellpose's spelling of the same switch — the reference
+        builds `CellposeModel(gpu=..., device=...)` with cellpose 4's defaults (dispatch.py:168-172), where it is True — and applies
+        when net_dtype is not given."""
+        if net_dtype is None:
+            net_dtype = "bfloat16" if use_bfloat16 else "float32"
         if not gpu or not torch.cuda.is_available():
             raise _lib.AlibyHipError("CellposeModel (HIP) needs a GPU: there is no CPU fallback in this build")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")

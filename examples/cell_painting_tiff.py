@@ -109,7 +109,9 @@ def main():
         cp_measure_feature_kwargs={"intensity": {"edge_measurements": False}},
     )
     print("pipeline steps:", list(base["steps"]))
-    setup = dict(pretrained_model=args.weights) if args.weights else dict(flows_override=analytic_flows_for(truth), run_network_with_override=True)
+    # net_dtype="bfloat16": the hand-written MFMA network (the default, float32, is the same module through PyTorch's own kernels)
+    setup = dict(net_dtype="bfloat16", **(dict(pretrained_model=args.weights) if args.weights
+                                          else dict(flows_override=analytic_flows_for(truth), run_network_with_override=True)))
 
     # 3. stamp it per position
     pipelines, names = [], []

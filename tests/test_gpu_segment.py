@@ -150,6 +150,9 @@ def test_network_forward_runs_and_is_deterministic(engine):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = CellposeModel(seed=3)
+        # the default is cellpose 4's (use_bfloat16=True): the hand-written MFMA network, not PyTorch's convolutions
+        assert model.fused is not None and model.net_dtype == torch.bfloat16
+        assert CellposeModel(seed=3, use_bfloat16=False).fused is None and CellposeModel(seed=3, net_dtype="float32").fused is None
     x = torch.from_numpy(f["pixels"][0]).cuda()  # [1,Y,X]
     dP1, p1 = model.run_network(x)
     dP2, p2 = model.run_network(x)
