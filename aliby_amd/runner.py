@@ -58,6 +58,14 @@ def _signature(pipeline: dict):
 _STEPS: list = []  # [(init_step_fn, step_name, parameters snapshot, fn)], most recently used last
 
 
+def _same_parameters(a, b) -> bool:
+    """a == b for step parameter dicts; values that do not compare to a plain bool (arrays, tensors) count as different."""
+    try:
+        return bool(a == b)
+    except (ValueError, RuntimeError, TypeError):
+        return False
+
+
 class _SharedSteps:
     """Step objects that hold no per-position state (segmenters: the network and its workspaces; extract partials) are built
     once per distinct parameter dict and shared by every position, instead of once per position as N single calls would —
@@ -72,7 +80,7 @@ class _SharedSteps:
             return self.init_step_fn(step_name, parameters, other)  # per-position state (the image, the running labels)
         for k in range(len(_STEPS) - 1, -1, -1):
             maker, name, params, fn = _STEPS[k]
-            if maker is self.init_step_fn and name == step_name and params == parameters:
+            if maker is self.init_step_fn and name == step_name and _same_parameters(params, parameters):
                 _STEPS.append(_STEPS.pop(k))
                 return fn
         fn = self.init_step_fn(step_name, parameters, other)
