@@ -197,6 +197,9 @@ def release_pinned():
     their device workspaces)."""
     _RINGS.clear()
     _STEPS.clear()
+    from aliby_amd.segment import dispatch
+
+    dispatch._MODELS.clear()
 
 
 _Product = ex.LazyProduct

@@ -42,13 +42,38 @@ def _as_one_block(blocks):
     return torch.as_strided(first, (sum(b.shape[0] for b in blocks), *first.shape[1:]), first.stride())
 
 
+_MODELS: list = []  # [(gpu, device, setup parameters, CellposeModel)], most recently used last
+
+
+def _model_for(gpu, device, setup_params):
+    """The CellposeModel for these parameters, built once per process: the reference builds one per position
+    (init_step -> dispatch_segmenter -> CellposeModel(...), pipe.py:47-77), which costs this build ~50 ms of weight packing and
+    workspace allocation per position — three quarters of a 1024^2 position's run_pipeline_and_post call.  The model keeps no
+    state between evals; the last 4 parameter sets are kept, `aliby_amd.runner.release_pinned()` drops them."""
+    from aliby_amd.segment.cellpose_hip import CellposeModel
+
+    def same(a, b):
+        try:
+            return bool(a == b)
+        except (ValueError, RuntimeError, TypeError):  # (arrays / tensors among the values)
+            return False
+
+    for k in range(len(_MODELS) - 1, -1, -1):
+        g, d, sp, model = _MODELS[k]
+        if g == gpu and d == device and same(sp, setup_params):
+            _MODELS.append(_MODELS.pop(k))
+            return model
+    model = CellposeModel(gpu=gpu, device=device, **setup_params)
+    _MODELS.append((gpu, device, dict(setup_params), model))
+    del _MODELS[:-4]
+    return model
+
+
 def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, **kwargs) -> callable:
     if kind in ("nahual_baby", "nahual_cellpose", "nahual_spotiflow") or (kind or "").startswith("nahual"):
         raise NotImplementedError(f"segmenter kind '{kind}' is a remote Nahual service (SURVEY §2 row 6): out of scope")
     if kind != "cellpose":
         raise Exception(f"Invalid segmentation method {kind}")
-
-    from aliby_amd.segment.cellpose_hip import CellposeModel
 
     # Extension (not in the reference): per_tile=True returns one label image per tile, the container BABY's parser hands
     # the reference's engine (list of [Y,X] masks, extract.py:271-281), instead of collapsing the tile axis as a Z axis
@@ -58,7 +83,7 @@ def dispatch_segmenter(kind: str, channel_to_segment: int, address: str = None, 
     setup_params = dict(kwargs.get("setup_params", {}))
     gpu = setup_params.pop("gpu", True)
     device = setup_params.pop("device", None)
-    model = CellposeModel(gpu=gpu, device=device, **setup_params)
+    model = _model_for(gpu, device, setup_params)
 
     def _device_block(pixels):
         """host array / device tensor [F,C,Z,Y,X] of any real dtype -> device tensor the model takes (uint16 stays uint16,

@@ -449,3 +449,28 @@ def test_dynamics_do_not_depend_on_the_order_of_the_foreground_list(engine, monk
         want = cr.compute_masks(d, p)
         assert np.array_equal(ref[k].cpu().numpy(), want), k
         assert np.array_equal(got[k].cpu().numpy(), want), (k, "reversed list")
+
+
+@pytest.mark.gpu
+def test_segmenters_of_equal_parameters_share_one_model(engine):
+    """init_step builds a segmenter per position, as the reference does; the model behind it (weights packed, workspaces) is
+    built once per parameter set and process (segment/dispatch.py _model_for); other parameters get another model;
+    release_pinned() drops them."""
+    import warnings
+
+    from aliby_amd import runner
+    from aliby_amd.segment import dispatch
+
+    runner.release_pinned()
+    override = lambda x: None  # noqa: E731
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = dispatch.dispatch_segmenter("cellpose", 0, setup_params=dict(flows_override=override))
+        b = dispatch.dispatch_segmenter("cellpose", 1, setup_params=dict(flows_override=override))
+        c = dispatch.dispatch_segmenter("cellpose", 0, setup_params=dict(flows_override=override, seed=4))
+        d = dispatch.dispatch_segmenter("cellpose", 0, setup_params=dict(flows_override=lambda x: None))
+    assert a is not b and a.model is b.model and a.channel_to_segment == 0 and b.channel_to_segment == 1
+    assert c.model is not a.model and d.model is not a.model
+    assert len(dispatch._MODELS) == 3
+    runner.release_pinned()
+    assert dispatch._MODELS == []
