@@ -979,11 +979,19 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
         import gc
 
         manage_gc = gc.isenabled() and not measure and os.environ.get("ALIBY_MANAGE_GC", "1") != "0"
-        collected = [False]
+        collected = [False, 0]  # collected during this batch / collections so far
 
         def collect():
+            # the young generations every batch; everything every 16th batch, after which the survivors (the tables and states the
+            # call will return) are frozen too: a full collection otherwise walks all results so far — 3.7 ms per batch at 16
+            # batches, 10 ms at 64, quadratic over a long run
             t0 = time.perf_counter()
-            gc.collect()
+            collected[1] += 1
+            if collected[1] % 16:
+                gc.collect(1)
+            else:
+                gc.collect()
+                gc.freeze()
             collected[0] = True
             clock["gc_s"] += time.perf_counter() - t0
 

@@ -664,6 +664,13 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             cpu1 = hostinfo.cpu_stat()
+            try:  # (stability of long runs: resident set of the process and device memory torch holds, after the leg)
+                import resource
+
+                stats["max_rss_mb"] = int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024)
+                stats["device_reserved_mb"] = int(torch.cuda.memory_reserved() >> 20)
+            except Exception:
+                pass
             stats["cgroup_cpu"] = {k: cpu1[k] - cpu0.get(k, 0) for k in cpu1 if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")}
             rows = sum(r[0].num_rows for r in res if r[0] is not None)  # (None: ALIBY_ABLATE diagnostics)
             cols = len(res[0][0].column_names) if res[0][0] is not None else 0
