@@ -520,3 +520,23 @@ def test_run_positions_keeps_shared_steps_between_calls_and_leaves_the_collector
         runner.run_positions(pipes(1, fail=True), ["bad"], tmp_path / "out", init_step_fn=init, batch_size=2)
     assert gc.isenabled() and gc.get_freeze_count() == 0
     runner.release_pinned()
+
+
+def test_usable_cores_divides_the_share_among_local_ranks(monkeypatch):
+    """hostinfo.usable_cores: ALIBY_HOST_CORES wins; otherwise the cgroup quota / affinity mask of the node is divided by
+    LOCAL_WORLD_SIZE (torch.distributed.run sets it), never below one core."""
+    from aliby_amd import hostinfo
+
+    monkeypatch.delenv("ALIBY_HOST_CORES", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    alone = hostinfo.usable_cores()
+    assert alone >= 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert hostinfo.usable_cores() == max(1, alone // 2)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4096")
+    assert hostinfo.usable_cores() == 1
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
+    assert hostinfo.usable_cores() == alone
+    monkeypatch.setenv("ALIBY_HOST_CORES", "5")
+    assert hostinfo.usable_cores() == 5
+    assert set(hostinfo.cpu_stat()) >= set() and isinstance(hostinfo.cpu_stat(), dict)

@@ -150,3 +150,26 @@ def test_host_copy_on_several_threads_is_a_memcpy():
             dst = np.zeros(nbytes + 8, np.uint8)
             _lib.check(lib.aliby_host_copy(dst.ctypes.data, src.ctypes.data, nbytes, threads))
             assert np.array_equal(dst[:nbytes], src) and not dst[nbytes:].any()
+
+
+def test_native_writers_fail_loudly_on_a_path_they_cannot_open(tmp_path):
+    """Both encoders assemble the file in memory and write it in one piece (csrc/host_writers.hip File): a directory that does
+    not exist is an error with the path in it, nothing is left behind, and the next file from the same thread is intact."""
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    from aliby_amd.io import write as W
+
+    table = pa.table({"a": pa.array(np.arange(5.0)), "b": pa.array(np.arange(5, dtype=np.int64))})
+    lay = W.table_layout(table)
+    missing = tmp_path / "no" / "such" / "dir"
+    with pytest.raises(ValueError, match="cannot open"):
+        W.write_parquet_native(missing / "x.parquet", [(lay, 0, 5)])
+    with pytest.raises(ValueError, match="cannot open"):
+        W.write_npz_native(missing / "x.npz", {"arr_0": np.arange(4)})
+    assert not missing.exists()
+    W.write_parquet_native(tmp_path / "ok.parquet", [(lay, 1, 3)])
+    assert pq.read_table(tmp_path / "ok.parquet")["a"].to_pylist() == [1.0, 2.0, 3.0]
+    assert W.write_npz_native(tmp_path / "ok.npz", {"arr_0": np.arange(4)})
+    assert np.load(tmp_path / "ok.npz")["arr_0"].tolist() == [0, 1, 2, 3]
