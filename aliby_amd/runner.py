@@ -24,6 +24,7 @@ collective, the optional end-of-run gather of rows is `parallel.gather_rows`.
 
 from __future__ import annotations
 
+import functools
 import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -886,9 +887,12 @@ def _cat(tensors):
     return torch.cat(tensors, 0)
 
 
-def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_size: int = 64, init_step_fn=None,
-                  writers: int | None = None, shard: bool = True, measure: bool = False, stats: dict | None = None,
-                  writer_processes: int | bool | None = None, switch_interval: float | None = 2e-4):
+_RUN_LOCK = threading.Lock()
+
+
+def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_size: int = 64, init_step_fn=None,
+                   writers: int | None = None, shard: bool = True, measure: bool = False, stats: dict | None = None,
+                   writer_processes: int | bool | None = None, switch_interval: float | None = 2e-4):
     """`run_pipeline_and_post` for many positions: pipelines[i] / names[i] -> profiles/<names[i]>.parquet (+ step outputs).
 
     batch_size: positions per device batch (64: 1600 network tiles of a 1024^2 plate per batch, ~0.7 GB of pixels on the device and
@@ -1045,3 +1049,15 @@ def run_positions(pipelines, names, output_path, overwrite: bool = True, batch_s
         n = max(measured_from if len(batches) > 1 else len(todo), 1)
         return {phase: round(1e3 * sec / n, 4) for phase, sec in runner.measure.items()}
     return out
+
+
+@functools.wraps(_run_positions)
+def run_positions(*args, **kwargs):
+    with _RUN_LOCK:
+        return _run_positions(*args, **kwargs)
+
+
+run_positions.__doc__ = (_run_positions.__doc__ or "") + """
+
+    One call at a time per process: the calls of a process share the GPU, the step objects (segmenters with their device
+    workspaces), the page-locked arenas and process-wide interpreter settings; a second caller waits for the first."""

@@ -493,3 +493,47 @@ def test_run_positions_with_an_empty_position_and_a_large_object(tmp_path, engin
                 else:
                     assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (k, i, c)
     assert any(g.num_rows == 0 for g in got)
+
+
+def test_run_positions_from_other_threads_and_two_at_once(tmp_path, engine):
+    """A caller that is not the main thread (its own context, aliby_amd/_lib.py), and two callers at once (the second waits:
+    the calls of a process share segmenters, arenas and interpreter settings) — both get the tables single calls produce."""
+    import threading
+
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    fovs = [synth.make_fov(2, 80 + i, shape=(224, 256), n_channels=2, n_target=9) for i in range(6)]
+    override = _keyed_override(fovs)
+
+    def pipes(sel):
+        made = []
+        for i in sel:
+            p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1], features_to_extract=("sizeshape", "intensity"))
+            p["steps"]["tile"]["image_kwargs"] = {"source": fovs[i]["pixels"][None]}
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+            made.append(p)
+        return made
+
+    want = [run_pipeline_and_post(pipeline=p, pipeline_name=f"S{i}", output_path=tmp_path / "single")[0] for i, p in enumerate(pipes(range(6)))]
+    got, errors = {}, []
+
+    def call(tag, sel):
+        try:
+            got[tag] = run_positions(pipes(sel), [f"{tag}{i}" for i in sel], tmp_path / tag, batch_size=2)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=call, args=("A", [0, 1, 2])), threading.Thread(target=call, args=("B", [3, 4, 5]))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and set(got) == {"A", "B"}, errors
+    for tag, sel in (("A", [0, 1, 2]), ("B", [3, 4, 5])):
+        for res, i in zip(got[tag], sel):
+            assert res[0].schema.equals(want[i].schema) and res[0].num_rows == want[i].num_rows > 0
+            for c in want[i].column_names:  # (column by column: three normalised moments are NaN by definition)
+                x, y = res[0][c].to_numpy(zero_copy_only=False), want[i][c].to_numpy(zero_copy_only=False)
+                assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (tag, i, c)
