@@ -17,6 +17,7 @@ behind a small `Engine` class.  Remote Nahual steps and trackastra global steps 
 from __future__ import annotations
 
 import logging
+import threading
 from functools import partial
 from pathlib import Path
 from typing import Callable
@@ -258,6 +259,12 @@ def run_pipeline_return_state(pipeline: dict, steps_dir, init_step_fn: Callable)
     return state
 
 
+# Pipelines of one process run one at a time on the device: a segmenter's model (weights, workspaces) is shared by every caller
+# with the same parameters (segment/dispatch.py), and so are the dynamics' workspace and the runner's arenas.  Re-entrant: the
+# position-batched runner holds it for a whole run_positions call and runs fallback steps under it.
+DEVICE_LOCK = threading.RLock()
+
+
 def _run_pipeline_and_post_impl(pipeline: dict, pipeline_name: str, output_path, overwrite: bool = True, *,
                                 init_step_fn: Callable, post_state_hook: Callable | None = None):
     """One position: `profiles/<name>.parquet` (zstd), `steps/<name>/...`; an existing parquet is skipped
@@ -268,7 +275,8 @@ def _run_pipeline_and_post_impl(pipeline: dict, pipeline_name: str, output_path,
     if not overwrite and profiles_file.exists():
         logger.info(f"Skipping {pipeline_name}")
         return None, None
-    state = run_pipeline_return_state(pipeline, output_path / "steps" / pipeline_name, init_step_fn)
+    with DEVICE_LOCK:  # (one pipeline at a time per process: callers on several threads share the GPU and the segmenters' models)
+        state = run_pipeline_return_state(pipeline, output_path / "steps" / pipeline_name, init_step_fn)
     profiles = get_profiles_from_state(state, pipeline)
     profiles_file.parent.mkdir(parents=True, exist_ok=True)
     write_profiles(profiles, profiles_file)

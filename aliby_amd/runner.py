@@ -887,7 +887,7 @@ def _cat(tensors):
     return torch.cat(tensors, 0)
 
 
-_RUN_LOCK = threading.Lock()
+_RUN_LOCK = pipe_core.DEVICE_LOCK  # (shared with single run_pipeline_and_post calls of other threads)
 
 
 def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_size: int = 64, init_step_fn=None,

@@ -525,13 +525,20 @@ def test_run_positions_from_other_threads_and_two_at_once(tmp_path, engine):
         except Exception as e:  # noqa: BLE001
             errors.append((tag, repr(e)))
 
-    threads = [threading.Thread(target=call, args=("A", [0, 1, 2])), threading.Thread(target=call, args=("B", [3, 4, 5]))]
+    def single(tag, sel):  # the reference's own entry point from a third thread, while the other two are at it
+        try:
+            got[tag] = [run_pipeline_and_post(pipeline=p, pipeline_name=f"{tag}{i}", output_path=tmp_path / tag) for i, p in zip(sel, pipes(sel))]
+        except Exception as e:  # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=call, args=("A", [0, 1, 2])), threading.Thread(target=call, args=("B", [3, 4, 5])),
+               threading.Thread(target=single, args=("C", [1, 4]))]
     for t in threads:
         t.start()
     for t in threads:
         t.join(timeout=120)
-    assert not errors and set(got) == {"A", "B"}, errors
-    for tag, sel in (("A", [0, 1, 2]), ("B", [3, 4, 5])):
+    assert not errors and set(got) == {"A", "B", "C"}, errors
+    for tag, sel in (("A", [0, 1, 2]), ("B", [3, 4, 5]), ("C", [1, 4])):
         for res, i in zip(got[tag], sel):
             assert res[0].schema.equals(want[i].schema) and res[0].num_rows == want[i].num_rows > 0
             for c in want[i].column_names:  # (column by column: three normalised moments are NaN by definition)
