@@ -360,6 +360,8 @@ class BatchRunner:
                 blocks.append(getattr(tiler, method)(tp))
         if not all(f is fns[0] for f in fns) or not hasattr(fns[0], "batch"):
             return None
+        if len({tuple(b.shape[1:]) for b in blocks}) != 1:
+            return None  # frames of different sizes: one network / dynamics pass cannot hold them, the positions go one by one
         trace.mark("segment:blocks ready")
         return fns[0].batch(blocks, pinned_alloc=self._arena.alloc if self._arena is not None else None)
 

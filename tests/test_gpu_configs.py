@@ -544,3 +544,33 @@ def test_run_positions_from_other_threads_and_two_at_once(tmp_path, engine):
             for c in want[i].column_names:  # (column by column: three normalised moments are NaN by definition)
                 x, y = res[0][c].to_numpy(zero_copy_only=False), want[i][c].to_numpy(zero_copy_only=False)
                 assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (tag, i, c)
+
+
+def test_run_positions_with_positions_of_different_shapes_in_one_batch(tmp_path, engine):
+    """Positions whose frames differ in size share a batch's segmentation where they can and fall back to the per-position engine
+    for the steps that need one block: same tables as single calls."""
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    fovs = [synth.make_fov(2, 90, shape=(224, 256), n_channels=2, n_target=9), synth.make_fov(2, 91, shape=(192, 224), n_channels=2, n_target=7),
+            synth.make_fov(2, 92, shape=(224, 256), n_channels=2, n_target=8), synth.make_fov(2, 93, shape=(160, 320), n_channels=2, n_target=6)]
+    override = _keyed_override(fovs)
+
+    def pipes():
+        made = []
+        for f in fovs:
+            p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1], features_to_extract=("sizeshape", "intensity"))
+            p["steps"]["tile"]["image_kwargs"] = {"source": f["pixels"][None]}
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+            made.append(p)
+        return made
+
+    names = [f"M{i}" for i in range(len(fovs))]
+    want = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=tmp_path / "single")[0] for p, nm in zip(pipes(), names)]
+    got = run_positions(pipes(), names, tmp_path / "batched", batch_size=4)
+    for i, (res, w) in enumerate(zip(got, want)):
+        assert res[0].schema.equals(w.schema) and res[0].num_rows == w.num_rows > 0
+        for c in w.column_names:
+            x, y = res[0][c].to_numpy(zero_copy_only=False), w[c].to_numpy(zero_copy_only=False)
+            assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (i, c)
