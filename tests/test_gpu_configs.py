@@ -574,3 +574,33 @@ def test_run_positions_with_positions_of_different_shapes_in_one_batch(tmp_path,
         for c in w.column_names:
             x, y = res[0][c].to_numpy(zero_copy_only=False), w[c].to_numpy(zero_copy_only=False)
             assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (i, c)
+
+
+def test_run_positions_recovers_after_a_failing_position(tmp_path, engine):
+    """A position whose image cannot be read fails the call with the reader's error; the next call of the process works (the
+    device lock is free, the collector is back on, the arenas are usable)."""
+    import gc
+
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    fovs = [synth.make_fov(2, 95 + i, shape=(224, 256), n_channels=2, n_target=8) for i in range(3)]
+    override = _keyed_override(fovs)
+
+    def pipes(bad=None):
+        made = []
+        for i, f in enumerate(fovs):
+            p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1], features_to_extract=("sizeshape",))
+            p["steps"]["tile"]["image_kwargs"] = ({"source": str(tmp_path / "missing.tif"), "capture_order": "CYX"} if i == bad
+                                                  else {"source": f["pixels"][None]})
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+            made.append(p)
+        return made
+
+    names = ["E0", "E1", "E2"]
+    with pytest.raises(Exception) as err:
+        run_positions(pipes(bad=1), names, tmp_path / "bad", batch_size=2)
+    assert "missing.tif" in str(err.value), err.value
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    got = run_positions(pipes(), names, tmp_path / "good", batch_size=2)
+    assert [g[0].num_rows > 0 for g in got] == [True, True, True]
