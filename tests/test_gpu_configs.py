@@ -604,3 +604,46 @@ def test_run_positions_recovers_after_a_failing_position(tmp_path, engine):
     assert gc.isenabled() and gc.get_freeze_count() == 0
     got = run_positions(pipes(), names, tmp_path / "good", batch_size=2)
     assert [g[0].num_rows > 0 for g in got] == [True, True, True]
+
+
+def test_run_positions_monotile_timelapse_matches_single_calls(tmp_path, engine):
+    """Positions with three time points (Z = 3, one channel, monotile, masks saved every time point, history trimmed by `retain`)
+    through the position-batched runner against one run_pipeline_and_post per position: tables, metadata_tp, saved masks."""
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+
+    T, P = 3, 3
+    stacks, keyed = [], []
+    for p in range(P):
+        fovs = [synth.make_fov(4, 10 * p + t, shape=(160, 192), n_channels=1, n_z=3, n_target=6 + t + p) for t in range(T)]
+        stacks.append(np.stack([f["pixels"] for f in fovs]))  # [T,1,3,Y,X]
+        keyed += [dict(pixels=f["pixels"], nuclei=f["nuclei"]) for f in fovs]
+    override = _keyed_override(keyed)  # (keyed by the projected plane: any order of calls, any batch)
+    tree = {"None": {"None": ["sizeshape"]}, 0: {"max": ["intensity"]}}
+
+    def pipes():
+        return [{
+            "ntps": T,
+            "steps": {
+                "tile": {"image_kwargs": {"source": stacks[p]}, "tile_size": None},
+                "segment_cells": {"segmenter_kwargs": {"kind": "cellpose", "setup_params": {"flows_override": override}}, "channel_to_segment": 0},
+                "extract_cells": {"tree": tree},
+            },
+            "passed_data": {"extract_cells": [("masks", "segment_cells"), ("pixels", "tile")]},
+            "passed_methods": {"segment_cells": ("tile", "get_fczyx")},
+            "save": ("segment_cells",), "save_interval": 1, "retain": {"tile": 1},
+        } for p in range(P)]
+
+    names = [f"T{p}" for p in range(P)]
+    want = [run_pipeline_and_post(pipeline=pl, pipeline_name=nm, output_path=tmp_path / "single")[0] for pl, nm in zip(pipes(), names)]
+    got = run_positions(pipes(), names, tmp_path / "batched", batch_size=2)
+    for p, (res, w) in enumerate(zip(got, want)):
+        assert res[0].schema.equals(w.schema) and res[0].num_rows == w.num_rows > 0
+        assert sorted(set(res[0]["metadata_tp"].to_pylist())) == list(range(T))
+        for c in w.column_names:
+            x, y = res[0][c].to_numpy(zero_copy_only=False), w[c].to_numpy(zero_copy_only=False)
+            assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (p, c)
+        for t in range(T):
+            a = np.load(tmp_path / "batched" / "steps" / names[p] / "segment_cells" / f"{t:04d}.npz")["arr_0"]
+            b = np.load(tmp_path / "single" / "steps" / names[p] / "segment_cells" / f"{t:04d}.npz")["arr_0"]
+            assert np.array_equal(a, b), (p, t)
