@@ -911,6 +911,9 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
         from aliby_amd.pipe import init_step as init_step_fn
     if len(pipelines) != len(names):
         raise ValueError("pipelines and names must have the same length")
+    if len(set(names)) != len(names):  # (two positions of one name would write the same files from two writer threads)
+        dup = sorted({n for n in names if list(names).count(n) > 1})[:5]
+        raise ValueError(f"position names must be unique, got {dup} more than once")
     rank, world, _ = parallel.rank_world()
     mine = parallel.positions_for_rank(len(pipelines), rank, world) if shard else list(range(len(pipelines)))
     out = [(None, None)] * len(pipelines)
