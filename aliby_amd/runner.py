@@ -914,6 +914,28 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
     if len(set(names)) != len(names):  # (two positions of one name would write the same files from two writer threads)
         dup = sorted({n for n in names if list(names).count(n) > 1})[:5]
         raise ValueError(f"position names must be unique, got {dup} more than once")
+    # The cycle collector, first thing (the comment at `collect` below says why): even the loop over the positions right here
+    # allocates enough to trigger a full collection over everything the caller holds — 135 us per position instead of 5.
+    import gc
+
+    manage_gc = gc.isenabled() and not measure and os.environ.get("ALIBY_MANAGE_GC", "1") != "0"
+    if manage_gc:
+        gc.freeze()  # (no collection first: a full one is 50-100 ms with torch and pyarrow imported, and unfreeze undoes this)
+        gc.disable()
+    try:
+        return _run_positions_body(pipelines, names, output_path, overwrite, batch_size, init_step_fn, writers, shard, measure, stats,
+                                   writer_processes, switch_interval, manage_gc)
+    finally:
+        if manage_gc:
+            gc.enable()
+            gc.unfreeze()
+
+
+def _run_positions_body(pipelines, names, output_path, overwrite, batch_size, init_step_fn, writers, shard, measure, stats,
+                        writer_processes, switch_interval, manage_gc):
+    from aliby_amd import parallel
+
+    t_enter = __import__("time").perf_counter()
     rank, world, _ = parallel.rank_world()
     mine = parallel.positions_for_rank(len(pipelines), rank, world) if shard else list(range(len(pipelines)))
     out = [(None, None)] * len(pipelines)
@@ -925,6 +947,7 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
             pipe_core.logger.info(f"Skipping {names[i]}")
             continue
         todo.append(pos)
+    t_validated = __import__("time").perf_counter()
     batches, k = [], 0
     while k < len(todo):
         sig = _signature(todo[k].pipeline)
@@ -950,7 +973,9 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
         writer_processes = 0
     if writers is None:
         writers = int(os.environ.get("ALIBY_WRITERS", max(2, cores - writer_processes) if writer_processes else max(2, cores - 4)))
+    t_batched = __import__("time").perf_counter()
     runner = BatchRunner(init_step_fn, writers=writers, measure=measure, writer_processes=writer_processes)
+    t_runner = __import__("time").perf_counter()
     futures = []
     measured_from = 0
     try:
@@ -987,7 +1012,6 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
         # of a batch that had no such wait.  ALIBY_MANAGE_GC=0 leaves the collector alone.
         import gc
 
-        manage_gc = gc.isenabled() and not measure and os.environ.get("ALIBY_MANAGE_GC", "1") != "0"
         collected = [False, 0]  # collected during this batch / collections so far
 
         def collect():
@@ -1005,9 +1029,10 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
             clock["gc_s"] += time.perf_counter() - t0
 
         if manage_gc:
-            gc.freeze()  # (no collection first: a full one is 50-100 ms with torch and pyarrow imported, and unfreeze undoes this)
-            gc.disable()
             trace.BEFORE_BLOCK.append(collect)
+        clock["before_first_batch_s"] = time.perf_counter() - t_enter
+        clock["of_which_validate_s"], clock["of_which_batching_s"], clock["of_which_runner_s"] = (
+            t_validated - t_enter, t_batched - t_validated, t_runner - t_batched)
         for b, batch in enumerate(batches):
             t0 = time.perf_counter()
             if measure:
@@ -1040,13 +1065,13 @@ def _run_positions(pipelines, names, output_path, overwrite: bool = True, batch_
                          writer_processes=int(runner.writer_processes),
                          writer_thread_seconds={k: round(v, 3) for k, v in runner.thread_seconds.items()})
     finally:
+        t_close = __import__("time").perf_counter()
         runner.close()
+        if stats is not None:
+            stats["close_s"] = round(__import__("time").perf_counter() - t_close, 4)
         try:
-            if manage_gc:
-                if collect in trace.BEFORE_BLOCK:
-                    trace.BEFORE_BLOCK.remove(collect)
-                gc.enable()
-                gc.unfreeze()
+            if manage_gc and collect in trace.BEFORE_BLOCK:
+                trace.BEFORE_BLOCK.remove(collect)
             sys.setswitchinterval(interval)
         except NameError:
             pass
