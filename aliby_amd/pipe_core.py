@@ -275,14 +275,28 @@ def _run_pipeline_and_post_impl(pipeline: dict, pipeline_name: str, output_path,
     if not overwrite and profiles_file.exists():
         logger.info(f"Skipping {pipeline_name}")
         return None, None
-    with DEVICE_LOCK:  # (one pipeline at a time per process: callers on several threads share the GPU and the segmenters' models)
-        state = run_pipeline_return_state(pipeline, output_path / "steps" / pipeline_name, init_step_fn)
-    profiles = get_profiles_from_state(state, pipeline)
-    profiles_file.parent.mkdir(parents=True, exist_ok=True)
-    write_profiles(profiles, profiles_file)
-    if post_state_hook is not None:
-        post_state_hook(state, pipeline, output_path, pipeline_name)
-    return profiles, {}
+    # While the call runs, what the process allocated before it is out of the cycle collector's sight: a position allocates
+    # enough (18 k (object, instruction) pairs for 256 nuclei) to trigger full collections, and a full collection over a heap with
+    # torch, pyarrow and the caller's data in it is ~100 ms against the ~18 ms a position takes.  (Nothing is disabled: the
+    # collector keeps running over what the call itself allocates.  ALIBY_MANAGE_GC=0: hands off.)
+    import gc
+    import os
+
+    frozen = gc.isenabled() and gc.get_freeze_count() == 0 and os.environ.get("ALIBY_MANAGE_GC", "1") != "0"
+    if frozen:
+        gc.freeze()
+    try:
+        with DEVICE_LOCK:  # (one pipeline at a time per process: callers on several threads share the GPU and the segmenters' models)
+            state = run_pipeline_return_state(pipeline, output_path / "steps" / pipeline_name, init_step_fn)
+        profiles = get_profiles_from_state(state, pipeline)
+        profiles_file.parent.mkdir(parents=True, exist_ok=True)
+        write_profiles(profiles, profiles_file)
+        if post_state_hook is not None:
+            post_state_hook(state, pipeline, output_path, pipeline_name)
+        return profiles, {}
+    finally:
+        if frozen:
+            gc.unfreeze()
 
 
 # ------------------------------------------------------------------------------------------------
