@@ -67,6 +67,17 @@ def _same_parameters(a, b) -> bool:
         return False
 
 
+def _shape_hint(pipeline: dict):
+    """Shape of a position's frames when its first tile step is fed from an array (anything with a .shape): positions of different
+    frame sizes cannot share a network / dynamics pass.  None for sources that have to be opened to know (files, zarr)."""
+    for name, params in pipeline["steps"].items():
+        if name.startswith("tile") and isinstance(params, dict):
+            source = (params.get("image_kwargs") or {}).get("source")
+            shape = getattr(source, "shape", None)
+            return tuple(shape) if shape is not None else None
+    return None
+
+
 class _SharedSteps:
     """Step objects that hold no per-position state (segmenters: the network and its workspaces; extract partials) are built
     once per distinct parameter dict and shared by every position, instead of once per position as N single calls would —
@@ -948,14 +959,12 @@ def _run_positions_body(pipelines, names, output_path, overwrite, batch_size, in
             continue
         todo.append(pos)
     t_validated = __import__("time").perf_counter()
-    batches, k = [], 0
-    while k < len(todo):
-        sig = _signature(todo[k].pipeline)
-        batch = [todo[k]]
-        while len(batch) < batch_size and k + len(batch) < len(todo) and _signature(todo[k + len(batch)].pipeline) == sig:
-            batch.append(todo[k + len(batch)])
-        batches.append(batch)
-        k += len(batch)
+    # positions that can share device steps — same signature, and the same frame shape where the source says it without being
+    # read (arrays) — are batched together wherever they stand in the list; groups in order of first appearance
+    groups: dict = {}
+    for pos in todo:
+        groups.setdefault((_signature(pos.pipeline), _shape_hint(pos.pipeline)), []).append(pos)
+    batches = [members[k : k + batch_size] for members in groups.values() for k in range(0, len(members), batch_size)]
     from aliby_amd import hostinfo
 
     cores = hostinfo.usable_cores()

@@ -568,12 +568,36 @@ def test_run_positions_with_positions_of_different_shapes_in_one_batch(tmp_path,
 
     names = [f"M{i}" for i in range(len(fovs))]
     want = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=tmp_path / "single")[0] for p, nm in zip(pipes(), names)]
-    got = run_positions(pipes(), names, tmp_path / "batched", batch_size=4)
+    from aliby_amd import runner
+
+    stats = {}
+    got = runner.run_positions(pipes(), names, tmp_path / "batched", batch_size=4, stats=stats)
+    assert stats["batches"] == 3  # array sources say their shape: [M0, M2] share a batch, M1 and M3 run alone
     for i, (res, w) in enumerate(zip(got, want)):
         assert res[0].schema.equals(w.schema) and res[0].num_rows == w.num_rows > 0
         for c in w.column_names:
             x, y = res[0][c].to_numpy(zero_copy_only=False), w[c].to_numpy(zero_copy_only=False)
             assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), (i, c)
+    # sources that do not say their shape (TIFF files here) land in one batch: the segmenter then takes them one by one
+    paths = []
+    for i, f in enumerate(fovs[:2]):
+        for c in range(2):
+            synth.write_tiff(tmp_path / f"img__{i}__{c}.tif", f["pixels"][c, 0])
+        paths.append([str(tmp_path / f"img__{i}__{c}.tif") for c in range(2)])
+
+    def file_pipes():
+        made = pipes()[:2]
+        for p, pp in zip(made, paths):
+            p["steps"]["tile"]["image_kwargs"] = {"source": {"key": Path(pp[0]).stem, "path": pp}, "regex": r".*img__([0-9])__([0-9])\.tif",
+                                                  "capture_order": "FC"}
+        return made
+
+    got_f = runner.run_positions(file_pipes(), ["F0", "F1"], tmp_path / "files", batch_size=4, stats=stats)
+    assert stats["batches"] == 1
+    for i in range(2):
+        for c in want[i].column_names:
+            x, y = got_f[i][0][c].to_numpy(zero_copy_only=False), want[i][c].to_numpy(zero_copy_only=False)
+            assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), ("files", i, c)
 
 
 def test_run_positions_recovers_after_a_failing_position(tmp_path, engine):
