@@ -39,10 +39,11 @@ def init(backend: str | None = None):
     return rank, world, local
 
 
-def gather_rows(values: torch.Tensor, meta: torch.Tensor, dst: int = 0, group=None):
+def gather_rows(values: torch.Tensor, meta: torch.Tensor, dst: int = 0, group=None, always_collective: bool = False):
     """values float64 [n_i, n_cols], meta int64 [n_i, k] on every rank -> concatenated (values, meta) in
-    rank order on `dst`, (None, None) elsewhere.  Single process: returns the inputs."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    rank order on `dst`, (None, None) elsewhere.  Single process: returns the inputs (always_collective=True runs the
+    collectives on a one-rank group all the same: the test that the RCCL calls themselves work on a one-GPU machine)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always_collective):
         return values, meta
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     out_dev = values.device

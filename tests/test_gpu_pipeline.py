@@ -465,3 +465,33 @@ def test_ratio_and_trap_functions_match_the_reference_module(engine):
 
     inst, res = process_tree_masks({0: {"max": ["ratio", "mean"]}}, lab, inputs["pixels"][None, :, None][:, :, :, 0] if False else inputs["pixels"][None], extract_tree)
     assert np.isnan(res[0]) and np.isfinite(res[1])
+
+
+@pytest.mark.gpu
+def test_gather_rows_through_rccl_on_a_one_rank_group(engine):
+    """The end-of-run exchange (aliby_amd/parallel.py gather_rows: all_gather of the row counts, padded gather of float64 rows and
+    int64 metadata) on backend "nccl" = RCCL with device tensors.  A one-GPU box cannot host two RCCL ranks, so the group has one;
+    the collectives still go through RCCL (communicator, kernels, dtypes), which the gloo world-size-2 test cannot show."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from aliby_amd import parallel
+
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        vals = torch.arange(12, dtype=torch.float64, device="cuda").reshape(4, 3) / 7
+        meta = torch.arange(16, dtype=torch.int64, device="cuda").reshape(4, 4)
+        v, m = parallel.gather_rows(vals, meta, always_collective=True)
+        assert v.is_cuda and torch.equal(v, vals) and torch.equal(m, meta)
+        v0, m0 = parallel.gather_rows(vals[:0], meta[:0], always_collective=True)  # a rank without rows
+        assert v0.shape == (0, 3) and m0.shape == (0, 4)
+        parallel.barrier()
+    finally:
+        dist.destroy_process_group()
