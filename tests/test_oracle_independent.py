@@ -327,3 +327,77 @@ def test_phase_normalised_drift_against_explicit_dft_and_closed_form():
         want = np.where(want > np.array(ref.shape) // 2, want - ref.shape, want)
         want = np.where(want < -(np.array(ref.shape) - 1) // 2 - 0.5, want + ref.shape, want)
         assert phase_cross_correlation(ref, mov, normalization="phase").tolist() == want.tolist()
+
+
+# ------------------------------------------------------------------------- radial distribution: brute force + Bellman-Ford
+def test_radial_distribution_against_brute_force_distances_and_relaxation():
+    """oracle/radial_restated.py (EDT for the distance to the edge, Dijkstra with a heap for the geodesic distance from the
+    centre, numpy scatter-adds for the ring / wedge statistics) against the same published definition computed another way:
+    the distance of every object pixel to every outside pixel, Bellman-Ford sweeps until nothing changes, and explicit
+    per-pixel accumulation — on a disc, an L-shape (where geodesic and straight-line distance differ), a ring with a hole
+    and a one-pixel object."""
+    from oracle import radial_restated as rr
+
+    def shapes():
+        yy, xx = np.mgrid[0:40, 0:44]
+        lab = np.zeros((40, 44), np.int32)
+        lab[(yy - 9) ** 2 + (xx - 10) ** 2 <= 36] = 1                      # disc
+        lab[22:36, 4:8] = 2                                                # L-shape
+        lab[32:36, 4:20] = 2
+        ring = ((yy - 12) ** 2 + (xx - 32) ** 2 <= 64) & ((yy - 12) ** 2 + (xx - 32) ** 2 >= 9)
+        lab[ring] = 3                                                      # ring with a hole
+        lab[30, 40] = 4                                                    # a single pixel
+        return lab
+
+    lab = shapes()
+    rng = np.random.default_rng(11)
+    img = rng.integers(50, 4000, lab.shape).astype(np.float64)
+    bins_n = 4
+    got = rr.get_radial_distribution(lab, img, scaled=True, bin_count=bins_n)
+
+    edge_step, diag_step = math.sqrt(0.5), 1.0
+    for k, L in enumerate([1, 2, 3, 4]):
+        m = lab == L
+        pts = np.argwhere(m)
+        outside = np.argwhere(~m)
+        d_edge = {tuple(p): float(np.sqrt(((outside - p) ** 2).sum(1)).min()) for p in pts}  # (the frame's border is not background)
+        best = max(d_edge.values())
+        centre = max((p for p in d_edge if d_edge[p] == best))  # last in raster order among the ties
+        dist = {p: math.inf for p in d_edge}
+        dist[centre] = 0.0
+        changed = True
+        while changed:  # Bellman-Ford over the 8-neighbourhood inside the object
+            changed = False
+            for (i, j) in dist:
+                for di, dj in itertools.product((-1, 0, 1), repeat=2):
+                    q = (i + di, j + dj)
+                    if (di or dj) and q in dist:
+                        nd = dist[q] + (diag_step if di and dj else edge_step)
+                        if nd < dist[(i, j)] - 1e-15:
+                            dist[(i, j)] = nd
+                            changed = True
+        tot = cnt = 0.0
+        ring_sum, ring_cnt = [0.0] * (bins_n + 1), [0.0] * (bins_n + 1)
+        wedges = [[[0.0, 0.0] for _ in range(8)] for _ in range(bins_n + 1)]
+        for p, d in dist.items():
+            if not math.isfinite(d):
+                continue
+            b = min(int(d / (d + d_edge[p] + 0.001) * bins_n), bins_n)
+            v = img[p]
+            tot += v
+            cnt += 1
+            ring_sum[b] += v
+            ring_cnt[b] += 1
+            wdg = (p[0] > centre[0]) + 2 * (p[1] > centre[1]) + 4 * (abs(p[0] - centre[0]) > abs(p[1] - centre[1]))
+            wedges[b][wdg][0] += v
+            wedges[b][wdg][1] += 1
+        for b in range(bins_n):
+            frac = ring_sum[b] / tot
+            mean_frac = frac / (ring_cnt[b] / cnt + np.finfo(float).eps)
+            means = [s / c for s, c in wedges[b] if c > 0]
+            cv = float(np.std(means) / np.mean(means)) if means else float("nan")
+            for stat, want in (("FracAtD", frac), ("MeanFrac", mean_frac), ("RadialCV", cv)):
+                have = got[f"RadialDistribution_{stat}_{b + 1}of{bins_n}"][k]
+                if ring_cnt[b] == 0 and stat == "RadialCV":
+                    continue  # (an empty ring: the restatement's convention for the CV of nothing is its own)
+                assert (math.isnan(want) and math.isnan(have)) or have == pytest.approx(want, rel=1e-12, abs=1e-12), (L, b, stat, have, want)
