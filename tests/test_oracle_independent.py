@@ -401,3 +401,60 @@ def test_radial_distribution_against_brute_force_distances_and_relaxation():
                 if ring_cnt[b] == 0 and stat == "RadialCV":
                     continue  # (an empty ring: the restatement's convention for the CV of nothing is its own)
                 assert (math.isnan(want) and math.isnan(have)) or have == pytest.approx(want, rel=1e-12, abs=1e-12), (L, b, stat, have, want)
+
+
+# ------------------------------------------------------------------------------------------- intensity: per-object loops
+def test_intensity_family_against_per_object_python(inputs):
+    """oracle/cp_measure_restated.get_intensity (labelled ndimage sums, lexsort order statistics) against the same quantities
+    written per object with plain Python / NumPy on the object's own pixel list: moments, extrema, the inner-boundary ("edge")
+    statistics with the boundary found pixel by pixel from the 4-neighbourhood, centres of mass and their displacement, and
+    CellProfiler's order statistics (value at position n·q of the sorted list, linearly interpolated; the last value when that
+    position is the last)."""
+    from oracle import cp_measure_restated as cm
+
+    labels = inputs["nuclei"].astype(np.int32)
+    img = inputs["pixels"][0, 0].astype(np.float64) if inputs["pixels"].ndim == 4 else inputs["pixels"][0].astype(np.float64)
+    got = cm.get_intensity(labels, img, edge_measurements=True)
+    H, W = labels.shape
+
+    def order_stat(sorted_vals, q):
+        n = len(sorted_vals)
+        pos = n * q
+        i = int(math.floor(pos))
+        if i < n - 1:
+            f = pos - i
+            return sorted_vals[i] * (1 - f) + sorted_vals[i + 1] * f
+        return sorted_vals[min(i, n - 1)]
+
+    for L in list(range(1, int(labels.max()) + 1))[:: max(1, int(labels.max()) // 12)]:
+        ys, xs = np.nonzero(labels == L)
+        vals = img[ys, xs]
+        k = L - 1
+        assert got["Intensity_IntegratedIntensity"][k] == pytest.approx(vals.sum(), rel=1e-12)
+        assert got["Intensity_MeanIntensity"][k] == pytest.approx(vals.mean(), rel=1e-12)
+        assert got["Intensity_StdIntensity"][k] == pytest.approx(math.sqrt(((vals - vals.mean()) ** 2).mean()), rel=1e-10)
+        assert got["Intensity_MinIntensity"][k] == vals.min() and got["Intensity_MaxIntensity"][k] == vals.max()
+        edge = []
+        for y, x in zip(ys, xs):  # inner boundary: a 4-neighbour (edge-replicated at the frame) carries another label
+            nb = [labels[min(max(y + dy, 0), H - 1), min(max(x + dx, 0), W - 1)] for dy, dx in ((-1, 0), (1, 0), (0, -1), (0, 1))]
+            if any(v != L for v in nb):
+                edge.append(img[y, x])
+        edge = np.asarray(edge)
+        assert got["Intensity_IntegratedIntensityEdge"][k] == pytest.approx(edge.sum(), rel=1e-12)
+        assert got["Intensity_MeanIntensityEdge"][k] == pytest.approx(edge.mean(), rel=1e-12)
+        assert got["Intensity_StdIntensityEdge"][k] == pytest.approx(math.sqrt(((edge - edge.mean()) ** 2).mean()), rel=1e-10)
+        assert got["Intensity_MinIntensityEdge"][k] == edge.min() and got["Intensity_MaxIntensityEdge"][k] == edge.max()
+        cx, cy = xs.mean(), ys.mean()
+        wx, wy = (xs * vals).sum() / vals.sum(), (ys * vals).sum() / vals.sum()
+        assert got["Location_CenterMassIntensity_X"][k] == pytest.approx(wx, rel=1e-12)
+        assert got["Location_CenterMassIntensity_Y"][k] == pytest.approx(wy, rel=1e-12)
+        assert got["Intensity_MassDisplacement"][k] == pytest.approx(math.hypot(cx - wx, cy - wy), rel=1e-9, abs=1e-12)
+        sv = np.sort(vals)
+        med = order_stat(sv, 0.5)
+        assert got["Intensity_LowerQuartileIntensity"][k] == pytest.approx(order_stat(sv, 0.25), rel=1e-12)
+        assert got["Intensity_MedianIntensity"][k] == pytest.approx(med, rel=1e-12)
+        assert got["Intensity_UpperQuartileIntensity"][k] == pytest.approx(order_stat(sv, 0.75), rel=1e-12)
+        assert got["Intensity_MADIntensity"][k] == pytest.approx(order_stat(np.sort(np.abs(vals - med)), 0.5), rel=1e-12, abs=1e-12)
+        # position of the maximum: the last raster occurrence among ties
+        at = np.nonzero(vals == vals.max())[0][-1]
+        assert (got["Location_MaxIntensity_X"][k], got["Location_MaxIntensity_Y"][k]) == (xs[at], ys[at])
