@@ -458,3 +458,36 @@ def test_intensity_family_against_per_object_python(inputs):
         # position of the maximum: the last raster occurrence among ties
         at = np.nonzero(vals == vals.max())[0][-1]
         assert (got["Location_MaxIntensity_X"][k], got["Location_MaxIntensity_Y"][k]) == (xs[at], ys[at])
+
+
+# ---------------------------------------------------------------------------------------------- Feret diameters: no hull
+def test_feret_diameters_without_a_convex_hull(inputs):
+    """oracle/cp_measure_restated.feret_diameters (qhull + per-edge widths) against a search that never builds a hull: the largest
+    distance between any two pixels of the object, and the smallest width of the pixel set over the directions of ALL pixel
+    pairs (the hull's edges are among them, so the minimum is the same)."""
+    from oracle import cp_measure_restated as cm
+
+    labels = inputs["nuclei"].astype(np.int32)
+    checked = 0
+    for L in range(1, int(labels.max()) + 1):
+        ys, xs = np.nonzero(labels == L)
+        if not (5 <= len(ys) <= 600):
+            continue
+        pts = np.stack([ys, xs], 1).astype(float)
+        d = pts[:, None, :] - pts[None, :, :]
+        fmax = float(np.sqrt((d ** 2).sum(-1)).max())
+        best = math.inf
+        for i in range(len(pts)):
+            e = pts - pts[i]                                   # directions p_i -> p_j
+            ln = np.hypot(e[:, 0], e[:, 1])
+            ok = ln > 0
+            u = e[ok] / ln[ok, None]
+            # signed distance of every pixel from the line through p_i with direction u: one row per direction
+            w = u[:, 0:1] * (pts[None, :, 1] - pts[i, 1]) - u[:, 1:2] * (pts[None, :, 0] - pts[i, 0])
+            best = min(best, float((w.max(1) - w.min(1)).min()))
+        fmin_o, fmax_o = cm.feret_diameters(labels == L)
+        assert fmax_o == pytest.approx(fmax, rel=1e-12) and fmin_o == pytest.approx(best, rel=1e-9, abs=1e-9), (L, fmin_o, best)
+        checked += 1
+        if checked == 6:
+            break
+    assert checked >= 3
