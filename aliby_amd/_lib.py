@@ -20,6 +20,7 @@ LIB_PATH = Path(os.environ["ALIBY_HIP_LIB"]) if os.environ.get("ALIBY_HIP_LIB") 
 
 OK, ERR_INVALID, ERR_OVERFLOW, ERR_HIP, ERR_TOO_LARGE, ERR_UNSUPPORTED = range(6)
 U16, F32 = 0, 1
+U8W = 4  # uint8 / bool pixels in uint16 storage: texture's grey level is the value itself (ALIBY_U8W)
 U64, F64 = 2, 3  # aliby_reduce_z output dtypes (NumPy's result types for uint16 add / divide)
 RED_MAX, RED_ADD, RED_DIV = 0, 1, 2
 

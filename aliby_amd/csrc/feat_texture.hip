@@ -34,16 +34,17 @@ struct TextureArgs {
   int cap_cells; // 16-bit cell counters that fit the key area (0: dense path off, an area could overflow 16 bits)
   unsigned char* gscratch;
   int scale, gray_levels;
+  int grey_shift;  // 8: uint16 pixels; 0: uint8 pixels in uint16 storage (ALIBY_U8W)
   double* out;
   int ld, col0;
 };
 
-__device__ __forceinline__ int grey_of(unsigned short v, int gl) {
-  int q = v >> 8;
+__device__ __forceinline__ int grey_of(unsigned short v, int gl, int shift) {
+  int q = v >> shift;
   if (gl != 256) q = (int)((double)q / 255.0 * (double)(gl - 1));
   return q;
 }
-__device__ __forceinline__ int grey_of(float v, int gl) {
+__device__ __forceinline__ int grey_of(float v, int gl, int) {
   double x = rint((double)v * 255.0);
   x = fmin(fmax(x, 0.0), 255.0);
   int q = (int)x;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_texture(TextureArgs a) {
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * (int)blockDim.x;
         if (i >= npix) break;
-        const int q = lb[u] == L ? grey_of(pv[u], a.gray_levels) : 0;
+        const int q = lb[u] == L ? grey_of(pv[u], a.gray_levels, a.grey_shift) : 0;
         g[i] = (unsigned char)q;
         gmax = max(gmax, q);
       }
@@ -340,7 +341,7 @@ extern "C" int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, co
   ARG_CHECK(ctx != nullptr, "ctx is NULL");
   if (n_obj == 0) return ALIBY_OK;
   ARG_CHECK(labels && planes && table_dev && out, "NULL argument");
-  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32, "dtype must be ALIBY_U16 or ALIBY_F32");
+  ARG_CHECK(dtype == ALIBY_U16 || dtype == ALIBY_F32 || dtype == ALIBY_U8W, "dtype must be ALIBY_U16, ALIBY_U8W or ALIBY_F32");
   ARG_CHECK(channel >= 0 && channel < C, "channel out of range");
   ARG_CHECK(F > 0 && Y > 0 && X > 0 && max_h >= 0 && max_w >= 0 && max_area >= 0, "bad shape");
   ARG_CHECK(scale >= 1 && gray_levels >= 2 && gray_levels <= 256, "scale >= 1 and 2 <= gray_levels <= 256");
@@ -349,6 +350,8 @@ extern "C" int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, co
   a.labels = labels; a.planes = planes; a.F = F; a.C = C; a.Y = Y; a.X = X; a.channel = channel;
   a.tab = table_dev; a.n_obj = n_obj; a.scale = scale; a.gray_levels = gray_levels;
   a.out = out; a.ld = ld; a.col0 = col0;
+  a.grey_shift = dtype == ALIBY_U8W ? 0 : 8;
+  if (dtype == ALIBY_U8W) dtype = ALIBY_U16;
   a.cap_pix = (int)(((size_t)max_h * max_w + 15) & ~(size_t)15);
   int ck = 2048;  // >= 4096 16-bit cells for the direct-counting path (K <= 90 distinct grey levels)
   while (ck < max_area) ck <<= 1;

@@ -49,17 +49,23 @@ def to_device_u16(a) -> torch.Tensor:
 
 
 def to_device_planes(a) -> tuple[torch.Tensor, int]:
-    """Pixels -> (tensor, dtype code).  <=16-bit unsigned ints stay uint16; everything else is f32."""
+    """Pixels -> (tensor, dtype code).  <=16-bit unsigned ints are stored as uint16 (uint8 / bool with the code U8W, so that the
+    texture kernel takes their grey level as skimage.util.img_as_ubyte does: unchanged); everything else is f32."""
     if isinstance(a, torch.Tensor):
         if a.dtype == torch.uint16:
             return a.cuda().contiguous(), _lib.U16
         if a.dtype == torch.uint8:
-            return a.cuda().to(torch.int32).to(torch.uint16).contiguous(), _lib.U16
+            return a.cuda().to(torch.int32).to(torch.uint16).contiguous(), _lib.U8W
         return a.cuda().to(torch.float32).contiguous(), _lib.F32
     a = np.asarray(a)
     if a.dtype in (np.uint16, np.uint8, np.bool_):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint16)).cuda(), _lib.U16
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint16)).cuda(), _lib.U16 if a.dtype == np.uint16 else _lib.U8W
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda(), _lib.F32
+
+
+def _kdt(dtype: int) -> int:
+    """dtype code as the kernels other than texture take it (U8W planes are uint16 storage)."""
+    return _lib.U16 if dtype == _lib.U8W else dtype
 
 
 @dataclass
@@ -338,7 +344,7 @@ class FeatureEngine:
         with self.timed("intensity"):
           _lib.check(
             self.lib.aliby_features_intensity(
-                self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel), _ptr(table.dev),
+                self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(channel), _ptr(table.dev),
                 table.n_obj, table.max_area, 1 if edge_measurements else 0, _ptr(out), out.stride(0), col0,
                 _stream_ptr(),
             )
@@ -387,7 +393,7 @@ class FeatureEngine:
         with self.timed("radial_zernikes" if weighted else "zernike"):
             _lib.check(
                 self.lib.aliby_features_zernike(
-                    self.ctx.handle, _ptr(labels), _ptr(planes) if weighted else 0, dtype if weighted else 0, F, Cn, Y, X,
+                    self.ctx.handle, _ptr(labels), _ptr(planes) if weighted else 0, _kdt(dtype) if weighted else 0, F, Cn, Y, X,
                     int(channel) if weighted else 0, _ptr(table.dev), table.n_obj, _ptr(mec), 1 if weighted else 0,
                     _ptr(out), out.stride(0), col0, _stream_ptr(),
                 )
@@ -414,7 +420,7 @@ class FeatureEngine:
                 c0 = (C.c_int * n)(*col0s[k : k + n])
                 with self.timed("radial_zernikes"):
                     _lib.check(self.lib.aliby_features_radial_zernikes_multi(
-                        self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, ch, c0, n, _ptr(table.dev), table.n_obj,
+                        self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, ch, c0, n, _ptr(table.dev), table.n_obj,
                         _ptr(mec), _ptr(out), out.stride(0), _stream_ptr()))
             k += n
         return 60
@@ -459,7 +465,7 @@ class FeatureEngine:
         with self.timed("radial_distribution"):
             _lib.check(
                 self.lib.aliby_features_radial_distribution_rings(
-                    self.ctx.handle, _ptr(labels), _ptr(binmap), _ptr(planes), dtype, F, Cn, Y, X, int(channel),
+                    self.ctx.handle, _ptr(labels), _ptr(binmap), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(channel),
                     _ptr(table.dev), table.n_obj, int(bin_count), rings, _ptr(out), out.stride(0), col0, _stream_ptr(),
                 )
             )
@@ -481,7 +487,7 @@ class FeatureEngine:
         with self.timed("granularity"):
             _lib.check(
                 self.lib.aliby_features_granularity(
-                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel), _ptr(table.dev), table.n_obj,
+                    self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(channel), _ptr(table.dev), table.n_obj,
                     float(subsample_size), float(image_sample_size), int(element_size), L, 1 if image_mask == "objects" else 0,
                     _ptr(work), work.numel() * 8, _ptr(out), out.stride(0) if table.n_obj else max(L + col0, 1), col0, _stream_ptr(),
                 )
@@ -500,7 +506,7 @@ class FeatureEngine:
         with self.timed("cell_metrics"):
             _lib.check(
                 self.lib.aliby_features_cell(
-                    self.ctx.handle, _ptr(labels), _ptr(planes) if planes is not None else 0, dtype, F, Cn, Y, X,
+                    self.ctx.handle, _ptr(labels), _ptr(planes) if planes is not None else 0, _kdt(dtype), F, Cn, Y, X,
                     int(channel) if planes is not None else 0, _ptr(table.dev), table.n_obj, table.max_h, table.max_w,
                     table.max_area, _ptr(out), out.stride(0) if table.n_obj else 17, 0, _stream_ptr(),
                 )
@@ -512,7 +518,7 @@ class FeatureEngine:
         F, Cn, Y, X = planes.shape
         out = torch.full((max(table.n_obj, 1),), float("nan"), dtype=torch.float64, device=labels.device)
         with self.timed("cell_metrics"):
-            _lib.check(self.lib.aliby_features_cell_ratio(self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch0), int(ch1),
+            _lib.check(self.lib.aliby_features_cell_ratio(self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(ch0), int(ch1),
                                                           _ptr(table.dev), table.n_obj, table.max_area, _ptr(out), _stream_ptr()))
         return out[: table.n_obj]
 
@@ -522,7 +528,7 @@ class FeatureEngine:
         F, Cn, Y, X = planes.shape
         out = torch.empty((F, 2), dtype=torch.float64, device=labels.device)
         with self.timed("trap_background"):
-            _lib.check(self.lib.aliby_features_trap_background(self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(channel),
+            _lib.check(self.lib.aliby_features_trap_background(self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(channel),
                                                                _ptr(out), _stream_ptr()))
         return out
 
@@ -539,7 +545,7 @@ class FeatureEngine:
             if ch in e["done"]:
                 continue
             with self.timed("ranks"):
-                _lib.check(self.lib.aliby_object_ranks(self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch),
+                _lib.check(self.lib.aliby_object_ranks(self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(ch),
                                                        _ptr(table.dev), table.n_obj, table.max_area, _ptr(e["ranks"]),
                                                        _ptr(e["rmax"]), _stream_ptr()))
             e["done"].add(ch)
@@ -566,7 +572,7 @@ class FeatureEngine:
         with self.timed("coloc"):
             _lib.check(
                 self.lib.aliby_features_coloc_pairs(
-                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, spec.ctypes.data, len(pairs), _ptr(table.dev),
+                    self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, spec.ctypes.data, len(pairs), _ptr(table.dev),
                     table.n_obj, table.max_area, _ptr(out), out.stride(0), float(thr), float(scale_max),
                     _ptr(ranks) if ranks is not None else 0, _ptr(rmax) if rmax is not None else 0, _stream_ptr(),
                 )
@@ -583,7 +589,7 @@ class FeatureEngine:
         with self.timed("coloc"):
             _lib.check(
                 self.lib.aliby_features_coloc(
-                    self.ctx.handle, _ptr(labels), _ptr(planes), dtype, F, Cn, Y, X, int(ch0), int(ch1),
+                    self.ctx.handle, _ptr(labels), _ptr(planes), _kdt(dtype), F, Cn, Y, X, int(ch0), int(ch1),
                     _ptr(table.dev), table.n_obj, table.max_area, _ptr(out), out.stride(0), c("pearson"),
                     c("manders_fold"), c("rwc"), c("costes"), float(thr), float(scale_max),
                     _ptr(ranks) if ranks is not None else 0, _ptr(rmax) if rmax is not None else 0, _stream_ptr(),

@@ -44,15 +44,18 @@ class PlaneCache:
             # read uint16 or float32 planes.  Sums of uint16 are exact in float32 while Z * 65535 < 2^24 (Z <= 256): beyond
             # that the plane would silently lose bits, so it is refused.  "div" results carry float32 rounding (6e-8
             # relative, three orders inside the 1e-4 feature tolerance).
-            if op == _lib.RED_ADD and self.dtype == _lib.U16 and Z * 65535 >= (1 << 24):
+            integer = self.dtype in (_lib.U16, _lib.U8W)
+            if op == _lib.RED_ADD and integer and Z * 65535 >= (1 << 24):
                 raise NotImplementedError(f"reduce_z 'add' over Z={Z} uint16 planes exceeds the exact float32 range (Z <= 256)")
             dt = self.dtype if op == _lib.RED_MAX else _lib.F32
-            out = torch.empty((F, C, Y, X), dtype=torch.uint16 if dt == _lib.U16 else torch.float32,
+            # (the maximum over z of 8-bit values is still 8-bit: the code U8W stays on the plane for the texture kernel)
+            out = torch.empty((F, C, Y, X), dtype=torch.uint16 if dt != _lib.F32 else torch.float32,
                               device=self.tensor.device)
             with self.eng.timed("reduce_z"):
                 _lib.check(
-                    self.eng.lib.aliby_reduce_z(self.eng.ctx.handle, _ptr(self.tensor), self.dtype, F * C, Z, Y * X,
-                                                op, _ptr(out), dt, _stream_ptr())
+                    self.eng.lib.aliby_reduce_z(self.eng.ctx.handle, _ptr(self.tensor), _lib.U16 if integer else _lib.F32,
+                                                F * C, Z, Y * X, op, _ptr(out), _lib.U16 if dt != _lib.F32 else _lib.F32,
+                                                _stream_ptr())
                 )
         self._cache[red_z] = (out, dt)
         return out, dt

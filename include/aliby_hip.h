@@ -40,7 +40,9 @@ enum {
 };
 
 enum { ALIBY_U16 = 0, ALIBY_F32 = 1,
-       ALIBY_U64 = 2, ALIBY_F64 = 3 /* output dtypes of aliby_reduce_z only: NumPy's own result types */ };
+       ALIBY_U64 = 2, ALIBY_F64 = 3 /* output dtypes of aliby_reduce_z only: NumPy's own result types */,
+       ALIBY_U8W = 4 /* uint16 storage holding uint8 / bool pixels: aliby_features_texture only (their grey level is the value
+                        itself, skimage.util.img_as_ubyte leaves uint8 alone); every other entry takes such planes as ALIBY_U16 */ };
 
 /* reduce_z operators — extraction/core/functions/loaders.py:110-127 ("max","add","div";
  * "mean"/"median" are not ufuncs and raise in distributors.py:20-24). */
@@ -354,7 +356,7 @@ int aliby_features_radial_zernikes_multi(aliby_ctx* ctx, const uint16_t* labels,
                                          int n_obj, const double* mec_dev, double* out, int ld, void* stream);
 
 /* cp_measure "texture": 13 Haralick statistics x 4 directions (direction-major, 52 columns) of the
- * object's bbox crop quantised to 8-bit grey levels (uint16 >> 8; [0,1] floats -> rint(255 f)),
+ * object's bbox crop quantised to 8-bit grey levels (uint16 >> 8; ALIBY_U8W: the value; [0,1] floats -> rint(255 f)),
  * co-occurrence distance `scale` (3), zero grey level ignored (mahotas ignore_zeros=True). */
 int aliby_features_texture(aliby_ctx* ctx, const uint16_t* labels, const void* planes, int dtype,
                            int F, int C, int Y, int X, int channel, const aliby_object* table_dev,

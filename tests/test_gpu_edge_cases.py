@@ -64,6 +64,20 @@ def test_float32_planes_every_family(engine):
     _run_both({(0, 1): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}}}, [f["cells"]], pixels, multi=True)
 
 
+def test_uint8_planes_every_family(engine):
+    """8-bit sources: stored as uint16 on the device, but texture takes their grey level as img_as_ubyte does for uint8 (the
+    value itself, not value >> 8 — which would be zero everywhere); Z = 2 so that the max-projection carries the 8-bit mark."""
+    f = synth.make_fov(1, 9, shape=(176, 192), n_channels=2, n_z=2, n_target=12)
+    pixels = (f["pixels"] >> 6).clip(0, 255).astype(np.uint8)[None]  # [1,C,2,Y,X] uint8
+    assert pixels.max() > 100
+    tree = {0: {"max": ["intensity", "radial_zernikes", "texture", "radial_distribution", "mean", "median"], "add": ["mean"]},
+            1: {"max": ["texture"]}}
+    inst, res = _run_both(tree, [f["cells"]], pixels)
+    tex = [np.asarray(r["Entropy_3_00_256"], float) for r in res if isinstance(r, dict) and "Entropy_3_00_256" in r]
+    assert tex and any((t[np.isfinite(t)] > 0).any() for t in tex)  # (all-zero grey levels would give no entropy at all)
+    _run_both({(0, 1): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}}}, [f["cells"]], pixels, multi=True)
+
+
 def test_ragged_tiles_and_z_reduction(engine):
     """Three tiles with 0 / few / many objects and Z = 3: one max-projection on the device."""
     tiles = [synth.make_fov(4, k, shape=(160, 176), n_channels=2, n_z=3, n_target=n) for k, n in ((0, 10), (1, 4))]

@@ -185,7 +185,7 @@ def test_zernike_and_mec_match_oracle(engine, objset):
 
 
 @pytest.mark.parametrize("objset", ["nuclei", "cells"])
-@pytest.mark.parametrize("mode", ["u16", "f32_unit"])
+@pytest.mark.parametrize("mode", ["u16", "f32_unit", "u8"])
 def test_texture_matches_oracle(engine, objset, mode):
     import torch
     from oracle import texture_restated as tx
@@ -197,8 +197,12 @@ def test_texture_matches_oracle(engine, objset, mode):
     planes = f["pixels"][:, 0]
     if mode == "f32_unit":
         planes = (planes.astype(np.float32) / np.float32(20000.0)).clip(0, 1).astype(np.float32)
+    if mode == "u8":  # 8-bit sources: img_as_ubyte leaves them alone (no >> 8), in storage they are widened to uint16
+        planes = (planes >> 6).clip(0, 255).astype(np.uint8)
+        assert len(np.unique(planes)) > 100
     dl = to_device_u16(labels[None])
     dp, dt = to_device_planes(planes[None])
+    assert dt == {"u16": 0, "f32_unit": 1, "u8": 4}[mode]
     tab = engine.object_table(dl)
     names = feat.texture_names(3, 256)
     for ch in range(planes.shape[0]):
