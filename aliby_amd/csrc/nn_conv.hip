@@ -272,7 +272,15 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = NPL * PLANE * 16;
   static constexpr int PIX_PER_IT = 256 / NPL;
   static constexpr int ITERS = (RAW + PIX_PER_IT - 1) / PIX_PER_IT;  // staging loads per thread and tile
-  static constexpr int BATCH = (PACK && COUT >= 128) ? (ITERS + 2) / 3 : (CIN >= 64 ? (ITERS + 1) / 2 : ITERS);  // staging loads in flight per thread
+#ifndef C3_B32T
+#define C3_B32T 1  // diagnostics: batches of the 32-channel TALL window
+#endif
+#ifndef C3_B64T
+#define C3_B64T 4  // batches of the 64 -> 64 TALL window (20 loads per thread; measured 2 / 3 / 4 batches: 394 / 320 / 294 us per 288-tile
+                   // launch — ten or seven loads at once spill the resident weights)
+#endif
+  static constexpr int NBATCH = (PACK && COUT >= 128) ? 3 : (CIN >= 64 ? ((TALL && COUT == 64) ? C3_B64T : 2) : (TALL ? C3_B32T : 1));
+  static constexpr int BATCH = (ITERS + NBATCH - 1) / NBATCH;  // staging loads in flight per thread
   static constexpr int DEPTH = (CIN >= 64 && COUT >= 64) ? 4 : 6;  // pixel fragments in flight LDS -> VGPR ahead of their MFMAs
   static constexpr int DEPTH_POOL = (CIN >= 64 && COUT >= 64) ? 3 : 6;  // the pooling epilogue needs a few registers more
 };
@@ -292,6 +300,9 @@ struct ConvCfg {
 // NHWC -> NCHW float32, from the accumulators: a lane holds 16 of a pixel's 32 channels, its partner (lane ^ 32) the other
 // 16.  Products are summed octet by octet, then octet pairs, then the two halves: the order of k_out_head, so both paths give
 // the same bits.  OUT may be NULL then (nothing else reads the last unit's output: 0.9 GB per forward not written, not re-read).
+#ifndef C3_HACK
+#define C3_HACK 0  // diagnostics (scripts/phase_builds.sh): compile-time phase switches of this kernel, timing only
+#endif
 template <int CIN, int COUT, bool UP, bool POOL, int PK, bool TALL, bool PACK = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   static_assert(!PACK || (!UP && PK == 0), "packed launches: plain input, no fused projection");
@@ -312,7 +323,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
   {
     const bf16x8_t* wp = reinterpret_cast<const bf16x8_t*>(a.wpk) + (size_t)cb * 9 * KC * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < 9 * KC; ++i) wfrag[i] = wp[i * 64];
+    for (int i = 0; i < 9 * KC; ++i) {
+      if constexpr (C3_HACK & 256) { wfrag[i] = bf16x8_t{}; wfrag[i][0] = (__bf16)(float)(i + lane); } else wfrag[i] = wp[i * 64];
+    }
   }
   bf16x8_t pfrag[PK > 0 ? PK : 1];
   if constexpr (PK > 0) {
@@ -321,6 +334,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     for (int i = 0; i < PK; ++i) pfrag[i] = pp[i * 64];
   }
   uint4* const ldsP = lds + NPL * PLANE;
+  // bias: once per launch into LDS (a global load per pass sat in front of every pass's first MFMA: an exposed L2 round trip,
+  // 3-5 % of the launch by phase elimination); visible to every wave after the first tile's barriers
+  __shared__ float4 sbias[COUT / 4];
+  if (tid < COUT / 4) sbias[tid] = a.bias ? reinterpret_cast<const float4*>(a.bias)[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
   __shared__ float hconst[HEAD ? 2 * 32 + 4 : 1];  // head: scale, shift, bias (the weights are MFMA fragments in registers)
   HeadW hwf;
   if constexpr (HEAD) {
@@ -380,9 +397,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
     // (pass 0 before the prologue, pass p+1 while pass p is on the matrix cores: one pass worth of registers)
     uint4 rr[R][2];
     auto load_res = [&](int pass) { conv_load_res<R>(a, nimg, irow, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
-    if (a.res) load_res(0);
+    if (a.res && !(C3_HACK & 2)) load_res(0);
     CONV_STAMP(1);
-    __syncthreads();  // every wave is done reading the previous tile's planes
+    if constexpr (!(C3_HACK & 128)) __syncthreads();  // every wave is done reading the previous tile's planes
     CONV_STAMP(2);
     // ---- stage the raw window: BATCH 16-byte loads per thread in flight at once (unconditional, from clamped
     // addresses: no divergent branch around a load), then the prologue (BatchNorm affine + style shift + ReLU,
@@ -413,12 +430,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
           const int img = (snd && ok) ? g0 + 1 : g0;
           inside |= (unsigned)ok << u;
           later |= (unsigned)snd << u;
-          v[u] = inN[(unsigned)(((img * a.H + cy) * IW + min(max(c, 0), a.W - 1)) * a.cs + pl)];
+          if constexpr (C3_HACK & 1) v[u] = make_uint4(cy, c, img, 3);
+          else v[u] = inN[(unsigned)(((img * a.H + cy) * IW + min(max(c, 0), a.W - 1)) * a.cs + pl)];
         } else {
           const int gxi = x0 - 1 + lx;
           inside |= (unsigned)((unsigned)gy < (unsigned)a.H && (unsigned)gxi < (unsigned)a.W) << u;
           const int cx = min(max(gxi, 0), a.W - 1);
-          v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * a.cs + pl)];
+          if constexpr (C3_HACK & 1) v[u] = make_uint4(cy, cx, 2, 3);
+          else v[u] = inN[(unsigned)(((UP ? cy >> 1 : cy) * IW + (UP ? cx >> 1 : cx)) * a.cs + pl)];
         }
       }
 #pragma unroll
@@ -431,10 +450,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
           for (int k = 0; k < 4; ++k) shs[k] = ((later >> u) & 1u) ? sh1[k] : sh[k];
           o = conv_act8(v[u], sc, shs, 0u - ((inside >> u) & 1u));
         } else {
-          o = conv_act8(v[u], sc, sh, 0u - ((inside >> u) & 1u));
+          if constexpr (C3_HACK & 16) o = v[u]; else o = conv_act8(v[u], sc, sh, 0u - ((inside >> u) & 1u));
         }
         if (it0 + u == ITERS - 1 && p0 + (it0 + u) * PIX_PER_IT >= RAW) continue;  // only the last round can run past the window
-        lds[pl * PLANE + p0 + (it0 + u) * PIX_PER_IT] = o;
+        if constexpr (C3_HACK & 32) { if (o.x == 0x12345u) lds[pl * PLANE + p0 + (it0 + u) * PIX_PER_IT] = o; }
+        else lds[pl * PLANE + p0 + (it0 + u) * PIX_PER_IT] = o;
       }
     }
     if constexpr (PK > 0) {  // the projection's raw input tile: TH x TW pixels, 2*PK channel octets, no halo
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       }
     }
     CONV_STAMP(3);
-    __syncthreads();
+    if constexpr (!(C3_HACK & 128)) __syncthreads();
     CONV_STAMP(4);
 
 #pragma unroll
@@ -460,17 +480,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
       const int rbase = (rg * PASSES + pass) * R;  // first output row of this wave and pass inside the tile
       f32x16_t acc[R];
       {
-        float4 b4[4] = {};
-        if (a.bias) {
-          const float4* bp = reinterpret_cast<const float4*>(a.bias + c0);
+        float4 b4[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) b4[q] = bp[q];
-        }
-        conv_seed<R>(acc, b4, rr, a.res != nullptr);
+        for (int q = 0; q < 4; ++q) b4[q] = (C3_HACK & 64) ? make_float4(0.f, 0.f, 0.f, 0.f) : sbias[(c0 >> 2) + q];
+        conv_seed<R>(acc, b4, rr, a.res != nullptr && !(C3_HACK & 2));
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (pass + 1 < PASSES && a.res) load_res(pass + 1);
+      if (pass + 1 < PASSES && a.res && !(C3_HACK & 2)) load_res(pass + 1);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(C3_HACK & 8))
       conv_mfma<R, KC, (POOL ? cfg::DEPTH_POOL : cfg::DEPTH), PLANE, LW>(
           reinterpret_cast<const bf16x8_t*>(lds) + hh * PLANE + rbase * LW + px + second, wfrag, acc);
       if constexpr (PK > 0) {
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(ConvArgs a) {
           }
         }
       }
-      if (!HEAD || a.out) conv_store<R>(a, nimg, irow, y0 + rbase, gx, c0, acc);
+      if ((!HEAD || a.out) && (!(C3_HACK & 4) || acc[0][3] == 12345.f)) conv_store<R>(a, nimg, irow, y0 + rbase, gx, c0, acc);
       // ---- the next level's input, max_pool2d(OUT, 2, 2), straight from the accumulators: row pairs are in this
       // wave's registers, column pairs are neighbouring lanes (max commutes with the bf16 rounding)
       if constexpr (POOL) {
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(256, (DmaCfg<CIN, COUT, UP, PACK>::WAVES_PER_SIMD))
     }
     uint4 rr[R][2];
     auto load_res = [&](int pass) { conv_load_res<R>(a, nimg, irow, y0 + (rg * PASSES + pass) * R, gx, c0, rr); };
-    if (a.res) load_res(0);
+    if (a.res && !(C3_HACK & 2)) load_res(0);
     CONV_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed in R
     __syncthreads();                                   // ... and everyone's; the previous tile's reads of A are over
@@ -1327,8 +1345,13 @@ int launch_conv(aliby_ctx* ctx, ConvArgs& a, hipStream_t stream) {
   if constexpr (!UP && COUT >= 64) {
     static const int pack_on = [] { const char* e = getenv("ALIBY_CONV_PACK"); return e ? atoi(e) : 7; }();  // bit 0: 128-cout shapes, bit 1: 64-cout
     if ((pack_on & (COUT >= 128 ? 1 : 2)) && !a.pin && (a.W == 28 || a.W == 56 || a.W == 112) && a.N % (224 / a.W) == 0 &&
-        a.H % ConvCfg<CIN, COUT, false, true>::TH == 0)
+        a.H % ConvCfg<CIN, COUT, false, true>::TH == 0) {
+      if constexpr (CIN == 64 && COUT == 64) {
+        static const bool tall64 = [] { const char* e = getenv("ALIBY_CONV_TALL64"); return e ? atoi(e) != 0 : true; }();
+        if (tall64 && a.H % ConvCfg<CIN, COUT, true, true>::TH == 0) return launch_conv_reg<CIN, COUT, UP, true, true>(ctx, a, stream);
+      }
       return launch_conv_reg<CIN, COUT, UP, false, true>(ctx, a, stream);
+    }
   }
   if (CAN_TALL && !a.pin && a.H % (2 * ConvCfg<CIN, COUT, false>::TH) == 0) return launch_conv_reg<CIN, COUT, UP, CAN_TALL>(ctx, a, stream);
   return launch_conv_reg<CIN, COUT, UP, false>(ctx, a, stream);

@@ -10,7 +10,9 @@ from aliby_amd.extraction.engine import FeatureEngine, _ptr, _stream_ptr  # noqa
 
 eng = FeatureEngine()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 96
-for cin, cout, up, H in [(32, 32, 0, 224), (64, 32, 1, 224), (64, 64, 0, 112), (32, 64, 0, 112), (64, 128, 0, 56), (64, 128, 0, 28)]:
+PLAIN = len(sys.argv) > 2 and sys.argv[2] == "plain"  # the two register-staged shapes only, no MIOpen (phase builds)
+SHAPES = [(32, 32, 0, 224), (64, 32, 1, 224), (64, 64, 0, 112), (32, 64, 0, 112), (64, 128, 0, 56), (64, 128, 0, 28)]
+for cin, cout, up, H in ([SHAPES[0], SHAPES[2]] if PLAIN else SHAPES):
     ih = H // 2 if up else H
     x = torch.randn(N, ih, ih, cin, device="cuda").bfloat16()
     w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
@@ -38,6 +40,8 @@ for cin, cout, up, H in [(32, 32, 0, 224), (64, 32, 1, 224), (64, 64, 0, 112), (
         byts = x.numel() * 2 + out.numel() * 2 + (res.numel() * 2 if with_res else 0)
         fl = 2.0 * 9 * cin * cout * px
         print(f"conv {cin}->{cout} up={up} H={H} N={N} res={with_res}: {ms*1e3:8.1f} us  {byts/ms/1e9:7.2f} TB/s... {byts/ms/1e6/1e3:.2f} GB/ms  {fl/ms/1e9:8.1f} TFLOP/s", flush=True)
+    if PLAIN:
+        continue
     # MIOpen for comparison (bf16 channels_last, no fusion)
     xa = torch.randn(N, cin, H, H, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
     wa = w.bfloat16().contiguous(memory_format=torch.channels_last)
