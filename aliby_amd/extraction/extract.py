@@ -165,7 +165,9 @@ def _device_pixels(pixels):
     if isinstance(pixels, np.ndarray):
         hit = devcache.lookup(pixels)
         if hit is not None:
-            return hit[0], _lib.U16 if hit[0].dtype == torch.uint16 else _lib.F32
+            if hit[0].dtype == torch.uint16:
+                return hit[0], _lib.U8W if hit[1].get("eight_bit") else _lib.U16
+            return hit[0], _lib.F32
     return to_device_planes(pixels)
 
 

@@ -78,6 +78,9 @@ class Tiler:
         for k, v in parameters.to_dict().items():
             setattr(self, k, v)
         self.pixels = pixels
+        # 8-bit sources (uint8 / bool) are stored as uint16 on the device; the mark travels with the step's pixel arrays so that the
+        # texture kernel takes their grey level unchanged, as skimage.util.img_as_ubyte does for uint8 (engine.to_device_planes)
+        self.eight_bit = str(getattr(pixels, "dtype", "")) in ("uint8", "bool", "torch.uint8", "torch.bool")
         self.meta = meta
         self.channels = list(range(pixels.shape[-4]))
         if self.tile_size is not None:
@@ -220,11 +223,15 @@ class Tiler:
         if hasattr(block, "compute"):
             block = block.compute(scheduler="synchronous")
         if isinstance(block, torch.Tensor):
+            if block.dtype in (torch.uint8, torch.bool):
+                block = block.to(torch.int32).to(torch.uint16)
             if target is not None and tuple(target.shape) == tuple(block.shape) and block.dtype == target.dtype:
                 target.copy_(block, non_blocking=True)
                 return target
             return block.cuda()
         block = np.ascontiguousarray(block)
+        if block.dtype in (np.uint8, np.bool_):
+            block = block.astype(np.uint16)
         if block.dtype != np.uint16:
             raise NotImplementedError(
                 f"stager handles uint16 stacks (the reference's fixtures, SURVEY §3.3); got {block.dtype}"
@@ -318,7 +325,9 @@ class Tiler:
             host = host.astype(np.float64)
             host[flags.astype(bool)] = np.nan
             return host
-        return devcache.attach(host, dev, kind="pixels")
+        if self.eight_bit:
+            host = host.astype(np.uint8)  # (the dtype the reference's tiler hands on)
+        return devcache.attach(host, dev, kind="pixels", eight_bit=self.eight_bit)
 
     def get_tp_channel(self, tp: int, c: int, drift: bool = True) -> np.ndarray:
         return self.get_fczyx(tp)[:, c]

@@ -369,6 +369,57 @@ def test_run_positions_writes_what_single_calls_write(tmp_path, engine):
     assert (batched / "profiles" / f"{names[4]}.parquet").read_bytes() == (single / "profiles" / f"{names[4]}.parquet").read_bytes()
 
 
+def test_eight_bit_sources_through_the_pipeline(tmp_path, engine):
+    """uint8 stacks (8-bit TIFF plates): stored as uint16 on the device, handed on as uint8, and measured as the reference's
+    CPU path measures uint8 arrays — in particular `texture`, whose grey levels are the values themselves for uint8
+    (skimage.util.img_as_ubyte) and value >> 8 for uint16.  Single calls, the position-batched runner and the oracle agree."""
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+    from oracle import texture_restated as tx
+
+    fovs = [synth.make_fov(2, 140 + i, shape=(224, 256), n_channels=2, n_target=8) for i in range(3)]
+    px8 = [(f["pixels"] >> 6).clip(0, 255).astype(np.uint8) for f in fovs]
+    assert all(len(np.unique(p)) > 100 for p in px8)
+    override = _keyed_override([dict(nuclei=f["nuclei"], pixels=p.astype(np.uint16)) for f, p in zip(fovs, px8)])
+
+    def pipelines(widen):
+        out = []
+        for p8 in px8:
+            p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1],
+                                     features_to_extract=("sizeshape", "intensity", "texture"))
+            p["steps"]["tile"]["image_kwargs"] = {"source": (p8.astype(np.uint16) if widen else p8)[None]}
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+            out.append(p)
+        return out
+
+    names = [f"E{i}" for i in range(3)]
+    single = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=tmp_path / "s8")[0] for p, nm in zip(pipelines(False), names)]
+    batched = [r[0] for r in run_positions(pipelines(False), names, tmp_path / "b8", batch_size=3)]
+    wide = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=tmp_path / "s16")[0] for p, nm in zip(pipelines(True), names)]
+    for i, nm in enumerate(names):
+        assert single[i].num_rows == batched[i].num_rows == wide[i].num_rows > 0
+        with np.load(tmp_path / "s8" / "steps" / nm / "segment_nuclei" / "0000.npz") as z:
+            labels = z["arr_0"]
+        for c in single[i].column_names:
+            a = single[i][c].to_numpy(zero_copy_only=False)
+            b = batched[i][c].to_numpy(zero_copy_only=False)
+            w = wide[i][c].to_numpy(zero_copy_only=False)
+            if a.dtype.kind != "f":
+                assert np.array_equal(a, b) and np.array_equal(a, w), c
+                continue
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), c
+            if "/texture/" not in c:
+                assert np.allclose(a, w, rtol=1e-9, atol=1e-12, equal_nan=True), c  # (the same values in either storage)
+        for ch in (0, 1):
+            ref = tx.get_texture(labels, px8[i][ch].max(axis=0))
+            for key, want in ref.items():
+                got = single[i][f"{ch}/max/texture/{key}"].to_numpy(zero_copy_only=False)
+                assert np.allclose(got, want, rtol=1e-4, atol=1e-8, equal_nan=True), (nm, ch, key)
+            ent = single[i][f"{ch}/max/texture/Entropy_3_00_256"].to_numpy(zero_copy_only=False)
+            assert np.nanmax(ent) > 1.0  # (value >> 8 would have left one grey level: no entropy at all)
+
+
 def _same(a, b):
     if isinstance(a, dict):
         return isinstance(b, dict) and sorted(a) == sorted(b) and all(_same(a[k], b[k]) for k in a)
