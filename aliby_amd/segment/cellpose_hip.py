@@ -43,14 +43,16 @@ def pad_amounts(Ly, Lx, div=16, extra=1):
 
 
 def taper_mask(by, bx, sig=7.5):
-    def one(b):
-        bs = max(224, b)
-        xm = np.arange(bs)
-        xm = np.abs(xm - xm.mean())
-        m = 1 / (1 + np.exp((xm - (bs / 2 - 20)) / sig))
+    """cellpose's blending weights of a by x bx tile: the central crop of a square sigmoid window of side max(224, by, bx)."""
+    bs = max(224, by, bx)
+    xm = np.arange(bs)
+    xm = np.abs(xm - xm.mean())
+    m = 1 / (1 + np.exp((xm - (bs / 2 - 20)) / sig))
+
+    def crop(b):
         return m[bs // 2 - b // 2 : bs // 2 + b // 2 + b % 2]
 
-    return (one(bx) * one(by)[:, np.newaxis]).astype(np.float32)
+    return (crop(bx) * crop(by)[:, np.newaxis]).astype(np.float32)
 
 
 class CellposeModel:
@@ -179,13 +181,15 @@ class CellposeModel:
         return int(mx[0])
 
     # ------------------------------------------------------------------------------ network leg
-    def _geometry(self, Y, X):
-        key = (Y, X)
+    def _geometry(self, Y, X, bsize=None, tile_overlap=None):
+        bsize = self.bsize if bsize is None else int(bsize)
+        tile_overlap = self.tile_overlap if tile_overlap is None else float(tile_overlap)
+        key = (Y, X, bsize, tile_overlap)
         if key not in self._geom_cache:
             yp1, yp2, xp1, xp2 = pad_amounts(Y, X)
             Ly, Lx = Y + yp1 + yp2, X + xp1 + xp2
-            ys, by = tile_starts(Ly, self.bsize, self.tile_overlap)
-            xs, bx = tile_starts(Lx, self.bsize, self.tile_overlap)
+            ys, by = tile_starts(Ly, bsize, tile_overlap)
+            xs, bx = tile_starts(Lx, bsize, tile_overlap)
             self._geom_cache[key] = dict(
                 ypad1=yp1, xpad1=xp1, Ly=Ly, Lx=Lx, by=by, bx=bx, ny=len(ys), nx=len(xs),
                 ys=torch.from_numpy(ys).to(self.device), xs=torch.from_numpy(xs).to(self.device),
@@ -222,10 +226,12 @@ class CellposeModel:
         out = torch.where(x99 - x01 > 1e-3, (flat - x01) / (x99 - x01), torch.zeros_like(flat))
         return out.to(torch.float32).reshape(F, Y, X)
 
-    def run_network(self, img_u16: torch.Tensor, normalize: bool = True):
-        """uint16 [F,Y,X] -> (dP float32 [F,2,Y,X], cellprob float32 [F,Y,X]) through the U-Net."""
+    def run_network(self, img_u16: torch.Tensor, normalize: bool = True, bsize=None, tile_overlap=None, batch_size=None):
+        """uint16 [F,Y,X] -> (dP float32 [F,2,Y,X], cellprob float32 [F,Y,X]) through the U-Net.
+        bsize / tile_overlap / batch_size: this call's tile geometry and tiles per forward (default: the model's)."""
         F, Y, X = img_u16.shape
-        g = self._geometry(Y, X)
+        g = self._geometry(Y, X, bsize, tile_overlap)
+        batch_size = self.batch_size if batch_size is None else max(1, int(batch_size))
         lib, h = self.eng.lib, self.eng.ctx.handle
         # normalize=False: the raw values go to the network as float32, as cellpose does with its `normalize` switch off
         norm = self.normalize(img_u16) if normalize else (
@@ -238,13 +244,13 @@ class CellposeModel:
                                             _stream_ptr()))
         yt = torch.empty((ntiles, 3, g["by"], g["bx"]), dtype=torch.float32, device=self.device)
         with self.eng.timed("unet_forward"), torch.no_grad():
-            for i in range(0, ntiles, self.batch_size):
+            for i in range(0, ntiles, batch_size):
                 if self.fused is not None and g["by"] % 8 == 0 and g["bx"] % 8 == 0:
-                    self._forward_batch(tiles[i : i + self.batch_size], yt[i : i + self.batch_size])  # written in place
+                    self._forward_batch(tiles[i : i + batch_size], yt[i : i + batch_size])  # written in place
                 else:
-                    xb = tiles[i : i + self.batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
+                    xb = tiles[i : i + batch_size].to(self.net_dtype).contiguous(memory_format=torch.channels_last)
                     yb, _ = self.net(xb)
-                    yt[i : i + self.batch_size] = yb.to(torch.float32)
+                    yt[i : i + batch_size] = yb.to(torch.float32)
         dP = torch.empty((F, 2, Y, X), dtype=torch.float32, device=self.device)
         prob = torch.empty((F, Y, X), dtype=torch.float32, device=self.device)
         with self.eng.timed("average_tiles"):
@@ -254,10 +260,34 @@ class CellposeModel:
         return dP, prob
 
     # ------------------------------------------------------------------------------------- eval
+    # cellpose's other `eval` keywords (3.1 / 4.0 signatures) and the values at which they change nothing here: a caller who
+    # passes one of these goes through; any other value asks for something that is not built and raises instead of being dropped
+    _EVAL_NEUTRAL = {
+        "resample": (True,), "channels": (None, [0, 0], (0, 0)), "channel_axis": (None,), "invert": (False,), "rescale": (None, 1, 1.0),
+        "diameter": (None, 0, 0.0), "anisotropy": (None,), "flow3D_smooth": (0,), "augment": (False,), "compute_masks": (True,),
+        "progress": (None,), "interp": (True,), "dP_smooth": (0,),
+    }
+
     def eval(self, x, do_3D=False, stitch_threshold=0.0, normalize=True, z_axis=None, niter=None,
-             flow_threshold=0.4, cellprob_threshold=0.0, min_size=15, max_size_fraction=0.4, **unused):
+             flow_threshold=0.4, cellprob_threshold=0.0, min_size=15, max_size_fraction=0.4, bsize=None, tile_overlap=None,
+             batch_size=None, **other):
         """x: uint16 [F,Y,X] (device tensor or host array) -> (masks, flows, styles) like cellpose.
-        masks is a device uint16 tensor, [Y,X] when F == 1 ("Cellpose squeezes dims"), else [F,Y,X]."""
+        masks is a device uint16 tensor, [Y,X] when F == 1 ("Cellpose squeezes dims"), else [F,Y,X].
+        bsize / tile_overlap / batch_size: cellpose's per-call tile size, overlap and tiles per forward (default: the model's own
+        224 / 0.1 / 288; results do not depend on batch_size).  Keywords of cellpose's eval that are not built (diameter / rescale
+        resizing, invert, augment, ...) raise NotImplementedError unless they carry their neutral value; unknown ones TypeError."""
+        if other.get("diameter") not in (None, 0):
+            # diameter == the model's diam_mean (30 px for the cyto family, the checkpoint's own value when it carries one) is a
+            # rescale factor of one; any other diameter would resize the image before the network, which is not built
+            mean = (getattr(getattr(self, "net", None), "diam", None) or {}).get("diam_mean") or 30.0
+            if abs(float(other["diameter"]) - float(mean)) < 1e-6:
+                other = {**other, "diameter": None}
+        for k, v in other.items():
+            if k not in self._EVAL_NEUTRAL:
+                raise TypeError(f"eval() got an unexpected keyword argument {k!r}")
+            if not any(v is n or (n is not None and not isinstance(v, bool) and v == n) or (isinstance(n, bool) and v is n)
+                       for n in self._EVAL_NEUTRAL[k]):
+                raise NotImplementedError(f"eval({k}={v!r}) is not built: only {self._EVAL_NEUTRAL[k]} (no effect) are accepted")
         if do_3D:
             raise NotImplementedError("do_3D: hand the planes of the stack to eval as a batch and stitch them (segment/dispatch.py does)")
         if not isinstance(x, torch.Tensor):
@@ -275,7 +305,7 @@ class CellposeModel:
             normalize = True
         dP = prob = None
         if self.flows_override is None or self.run_network_with_override:
-            dP, prob = self.run_network(x, normalize=bool(normalize))
+            dP, prob = self.run_network(x, normalize=bool(normalize), bsize=bsize, tile_overlap=tile_overlap, batch_size=batch_size)
         if self.flows_override is not None:
             dP, prob = self.flows_override(x)
         labels, counts = dynamics.masks_from_flows(

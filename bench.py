@@ -66,6 +66,9 @@ def build_trees(channels, seg_channel=0, features=None):
     return mono, multi
 
 
+BSIZE = 224  # network tile size of this run (--bsize)
+
+
 def alg_bytes(kernel, B, C, Z, Y, X, n_obj, n_tiles_net):
     """Algorithmic bytes of one launch of a kernel group (every input byte touched once per
     stage, outputs once)."""
@@ -75,8 +78,8 @@ def alg_bytes(kernel, B, C, Z, Y, X, n_obj, n_tiles_net):
         "reduce_z": B * C * (Z + 1) * P * 2,
         "select_project": B * Z * P * 2 + B * P * 2,
         "normalize99": B * P * 2 * 2 + B * P * 4,
-        "make_tiles": B * P * 4 + n_tiles_net * 2 * 224 * 224 * 4,
-        "average_tiles": n_tiles_net * 3 * 224 * 224 * 4 + B * 3 * P * 4,
+        "make_tiles": B * P * 4 + n_tiles_net * 2 * BSIZE * BSIZE * 4,
+        "average_tiles": n_tiles_net * 3 * BSIZE * BSIZE * 4 + B * 3 * P * 4,
         "dynamics": B * (3 * P * 4 + P * 2),
         "object_table": B * P * 2 + n_obj * 32,  # (one pass: the largest labels come from the segmenter's counts)
         "intensity": B * P * 2 * 2 + n_obj * 21 * 8,
@@ -281,7 +284,7 @@ def build_rooflines(prof, model, args, B, C, Z, Y, X, n_obj, n_tiles_net, steps)
     net_ms = prof.get("unet_forward", {}).get("ms_total", 0.0) / max(steps, 1)
     hip_in_net_ms = sum(prof.get(k, {}).get("ms_total", 0.0) for k in ("fused_pointwise", "conv3x3_mfma", "conv3x3_mfma_deep", "conv3x3_mfma_head", "conv3x3_mfma_pair", "conv3x3_mfma_first_pair", "maxpool", "out_head",
                                                                        "first_conv", "conv1x1_mfma", "style")) / max(steps, 1)
-    net_flops = model.net.flops_per_pixel() * n_tiles_net * 224 * 224
+    net_flops = model.net.flops_per_pixel() * n_tiles_net * BSIZE * BSIZE
     mfma = {"unet_ms_per_step": round(net_ms, 3), "of_which_hand_written_hip_ms": round(hip_in_net_ms, 3), "unet_tflops": round(net_flops / (net_ms * 1e-3) / 1e12, 2) if net_ms else None,
             "dtype": args.net_dtype, "peak_tflops_dense": 2500.0 if args.net_dtype != "float32" else 157.3,
             "path": "hand-written HIP (libaliby_hip.so)" if model.fused is not None else "torch module (MIOpen) - A/B reference, not the product path"}
@@ -307,6 +310,8 @@ def main():
                     "plain torch module through MIOpen — an A/B reference for the network's numerics, NOT the product path; the line "
                     "then says so in mfma.path and carries no conv roofline")
     ap.add_argument("--net-batch", type=int, default=288, help="224x224 tiles per U-Net forward (the reference's batch_size knob)")
+    ap.add_argument("--bsize", type=int, default=224, help="network tile size: 224 = cellpose 3's (the residual U-Net's own family, "
+                    "the default and the headline); 256 = what cellpose 4's eval defaults to — 25 instead of 36 tiles per 1024^2 FOV")
     ap.add_argument("--time-every", type=int, default=7, help="bracket every n-th launch of the per-layer network kernels with HIP "
                     "events (they are launched ~600 times per step; 1 = every launch)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="informational: no per-kernel HIP events, so the network forward "
@@ -324,6 +329,8 @@ def main():
                     "a tile is one [C,Z,Y,X] stack.  Without it config 5 is the reference-faithful projected form")
     ap.add_argument("--host-procs", type=int, default=0, help="host processes for input generation / the CPU baseline (default: all)")
     args = ap.parse_args()
+    global BSIZE
+    BSIZE = args.bsize
     if "RANK" not in os.environ and args.gpus > 1:
         launch_ranks(args.gpus, sys.argv[1:])
     if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
@@ -363,7 +370,7 @@ def main():
         pipe = build_pipeline_steps(channels_to_segment={"nuclei": cfg["seg_channel"]}, channels_to_extract=channels, **kw)
         cpu = whole_tile(dict(pixels=base[0]["pixels"], nuclei=base[0]["nuclei"]), (base[0]["dP"], base[0]["prob"]),
                          pipe["steps"]["extract_nuclei"]["tree"], pipe["steps"].get("extractmulti_nuclei", {}).get("tree", {}),
-                         workers=procs, net_tiles=int(np.ceil(size / 224 * 1.2)) ** 2)
+                         workers=procs, net_tiles=int(np.ceil(size / BSIZE * 1.2)) ** 2)
 
     import torch
 
@@ -408,7 +415,7 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = CellposeModel(net_dtype=args.net_dtype, seed=0, flows_override=lambda x: (dP_true, prob_true),
-                              run_network_with_override=True, batch_size=args.net_batch)
+                              run_network_with_override=True, batch_size=args.net_batch, bsize=args.bsize)
     eng = model.eng
     torch.cuda.synchronize()
     n_tiles_net = B * model._geometry(Y, X)["ny"] * model._geometry(Y, X)["nx"]
@@ -576,6 +583,7 @@ def main():
                 "features": feats,
                 "segmentation": "U-Net forward with fixed-seed random weights (weights not obtainable offline; cost paid, output "
                                 "discarded) + dynamics on analytic flows of the synthetic ground truth",
+                "network_tiles": f"{n_tiles_net // B} tiles of {args.bsize} x {args.bsize} per FOV (tile_overlap 0.1), {args.net_batch} per forward",
                 "objects_last_step": int(table.n_obj),
                 "feature_vectors_per_s": round(tiles_per_s * float(table.n_obj) / B, 1),
                 "columns": n_cols,
@@ -636,7 +644,7 @@ def api_leg(args, cfg, base, channels, B, distinct, rank, world, dist, backend, 
         return out
 
     WRITERS = None  # aliby_amd.runner sizes its writer threads / processes from the host share (ALIBY_WRITERS / ALIBY_WRITER_PROCS)
-    SETUP = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch)
+    SETUP = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch, bsize=args.bsize)
     out_dir = Path(tempfile.mkdtemp(prefix=f"aliby_bench_r{rank}_"))
     try:
         with warnings.catch_warnings():
@@ -778,7 +786,7 @@ def main_volume(args):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = CellposeModel(net_dtype=args.net_dtype, seed=0, flows_override=lambda x: (dP_d, prob_d), run_network_with_override=True,
-                              batch_size=args.net_batch)
+                              batch_size=args.net_batch, bsize=args.bsize)
     eng = model.eng
     n_tiles_net = B * Z * model._geometry(Y, X)["ny"] * model._geometry(Y, X)["nx"]
     state = {"parity": 0}
@@ -940,7 +948,7 @@ def main_timelapse(args):
         reps = x.shape[0] // dP.shape[0]
         return dP.repeat(reps, 1, 1, 1), pr.repeat(reps, 1, 1)
 
-    setup = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch)
+    setup = dict(flows_override=override, run_network_with_override=True, net_dtype=args.net_dtype, batch_size=args.net_batch, bsize=args.bsize)
 
     def pipelines(t0, ntps):
         out = []

@@ -106,11 +106,17 @@ def pad_to_16(Ly, Lx, div=16, extra=1):
     return ypad1, ypad2, xpad1, xpad2
 
 
-def taper_mask(bsize=224, sig=7.5):
-    xm = np.arange(bsize)
-    xm = np.abs(xm - xm.mean())
-    m = 1 / (1 + np.exp((xm - (bsize / 2 - 20)) / sig))
-    return (m * m[:, np.newaxis]).astype(f32)
+def taper_mask(ly=224, lx=None, sig=7.5):
+    """cellpose transforms._taper_mask(ly, lx, sig): a square window of side max(224, ly, lx) — the product of two 1-D sigmoids
+    falling off 20 px before the edge — cropped about its centre to ly x lx.  (Tiles smaller than 224, i.e. small images, take the
+    CENTRE of the 224 window, not a narrower window.)"""
+    lx = ly if lx is None else lx
+    side = max(224, ly, lx)
+    d = np.abs(np.arange(side) - (side - 1) / 2.0)
+    w = 1.0 / (1.0 + np.exp((d - (side / 2 - 20)) / sig))
+    full = w * w[:, np.newaxis]
+    c = side // 2
+    return full[c - ly // 2 : c + ly // 2 + ly % 2, c - lx // 2 : c + lx // 2 + lx % 2].astype(f32)
 
 
 def make_tiles(img_chw, bsize=224, tile_overlap=0.1):
@@ -124,15 +130,15 @@ def make_tiles(img_chw, bsize=224, tile_overlap=0.1):
 
 def average_tiles(y_tiles, ys, xs, Ly, Lx):
     """Weighted average of overlapping tile outputs [ntiles, nout, b, b] -> [nout, Ly, Lx] (float32)."""
-    b = y_tiles.shape[-1]
-    mask = taper_mask(b)
+    by, bx = y_tiles.shape[-2:]
+    mask = taper_mask(by, bx)
     out = np.zeros((y_tiles.shape[1], Ly, Lx), f32)
     navg = np.zeros((Ly, Lx), f32)
     k = 0
     for y in ys:
         for x in xs:
-            out[:, y : y + b, x : x + b] += y_tiles[k] * mask
-            navg[y : y + b, x : x + b] += mask
+            out[:, y : y + by, x : x + bx] += y_tiles[k] * mask
+            navg[y : y + by, x : x + bx] += mask
             k += 1
     return out / navg
 

@@ -79,8 +79,10 @@ def test_dynamics_edge_cases(engine):
     assert n.tolist() == [0, int(got[1].max())]
 
 
-def test_normalize_tiles_blend_bit_exact(engine):
-    """normalize99 / make_tiles / average_tiles kernels vs the NumPy restatement (float32 bit-exact)."""
+@pytest.mark.parametrize("bsize,overlap", [(224, 0.1), (256, 0.1), (128, 0.25)])
+def test_normalize_tiles_blend_bit_exact(engine, bsize, overlap):
+    """normalize99 / make_tiles / average_tiles kernels vs the NumPy restatement (float32 bit-exact), at cellpose 3's tile
+    geometry (224, 0.1), cellpose 4's eval default (256) and an odd one: `eval(bsize=..., tile_overlap=...)` per call."""
     import torch
     from aliby_amd.segment.cellpose_hip import CellposeModel, pad_amounts, taper_mask, tile_starts
     from oracle import cellpose_restated as cr
@@ -98,17 +100,19 @@ def test_normalize_tiles_blend_bit_exact(engine):
     yp1, yp2, xp1, xp2 = pad_amounts(300, 520)
     assert (yp1, yp2, xp1, xp2) == cr.pad_to_16(300, 520)
     Ly, Lx = 300 + yp1 + yp2, 520 + xp1 + xp2
-    ys, by = tile_starts(Ly)
-    xs, bx = tile_starts(Lx)
-    ys_o, by_o = cr.tile_starts(Ly)
-    xs_o, bx_o = cr.tile_starts(Lx)
+    ys, by = tile_starts(Ly, bsize, overlap)
+    xs, bx = tile_starts(Lx, bsize, overlap)
+    ys_o, by_o = cr.tile_starts(Ly, bsize, overlap)
+    xs_o, bx_o = cr.tile_starts(Lx, bsize, overlap)
     assert ys.tolist() == ys_o.tolist() and xs.tolist() == xs_o.tolist() and (by, bx) == (by_o, bx_o)
-    assert np.array_equal(taper_mask(224, 224), cr.taper_mask(224))
+    assert np.array_equal(taper_mask(bsize, bsize), cr.taper_mask(bsize))
+    assert np.array_equal(taper_mask(216, 256), cr.taper_mask(216, 256)) and np.array_equal(taper_mask(176, 208), cr.taper_mask(176, 208))
     # tiles
     from aliby_amd import _lib
     from aliby_amd.extraction.engine import _ptr, _stream_ptr
 
-    g = model._geometry(300, 520)
+    g = model._geometry(300, 520, bsize, overlap)
+    assert (g["by"], g["bx"]) == (bsize, bsize)
     F = 3
     nt = F * g["ny"] * g["nx"]
     tiles = torch.empty((nt, 2, g["by"], g["bx"]), dtype=torch.float32, device="cuda")
@@ -120,7 +124,7 @@ def test_normalize_tiles_blend_bit_exact(engine):
     for k in range(F):
         padded = np.zeros((2, Ly, Lx), np.float32)
         padded[0, yp1 : yp1 + 300, xp1 : xp1 + 520] = norm[k]
-        want, _, _ = cr.make_tiles(padded)
+        want, _, _ = cr.make_tiles(padded, bsize, overlap)
         assert np.array_equal(got[k], want)
     # blending of arbitrary network outputs
     rng = np.random.default_rng(0)
@@ -254,6 +258,33 @@ def test_fused_unet_matches_module_forward(engine):
     unpaired.fused_head = False
     yd, _ = unpaired(x)
     assert torch.equal(ya, yd)
+
+
+@pytest.mark.parametrize("n,h,w", [(4, 256, 256), (3, 128, 128), (2, 176, 208), (5, 64, 96)])
+def test_fused_unet_at_other_tile_sizes(engine, n, h, w):
+    """The network at tile sizes other than cellpose 3's 224 x 224 — `eval(bsize=256)` (cellpose 4's default), small images
+    (one tile of the image's own padded size, a multiple of 16), odd batch sizes: the packed / tall / paired launch forms are
+    chosen per shape, so every choice is checked against the fp32 module forward."""
+    import torch
+    from aliby_amd.segment.fused_unet import FusedUNet
+    from aliby_amd.segment.unet import build_network
+
+    net = build_network(seed=6, device="cuda")
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    x = torch.randn(n, 2, h, w, generator=g).cuda().contiguous()
+    with torch.no_grad():
+        y_ref, s_ref = net(x)
+    y, s = FusedUNet(net, engine)(x)
+    assert y.shape == y_ref.shape == (n, 3, h, w)
+    err = float((y - y_ref).norm() / y_ref.norm())
+    assert err < 0.03, err
+    assert float((s - s_ref).norm() / s_ref.norm()) < 0.03
 
 
 def test_dynamics_large_mask_uses_global_scratch(engine):
@@ -474,3 +505,26 @@ def test_segmenters_of_equal_parameters_share_one_model(engine):
     assert len(dispatch._MODELS) == 3
     runner.release_pinned()
     assert dispatch._MODELS == []
+
+
+@pytest.mark.gpu
+def test_eval_keywords_of_cellpose_are_honoured_or_refused(engine):
+    """`segment(pixels, **kw)` hands its keywords to `model.eval` (dispatch.py:208-215).  Tile geometry per call is honoured and
+    changes the flows' blending only; keywords that would change the result in ways that are not built (diameter resizing,
+    augment, invert, ...) raise instead of being dropped; neutral values and cellpose-3 habits (channels=[0, 0]) pass."""
+    import torch
+    from aliby_amd.segment.cellpose_hip import CellposeModel
+
+    f = synth.make_fov(2, 3, shape=(300, 520), n_channels=1, n_target=20)
+    x = torch.from_numpy(f["pixels"][0, 0][None].copy()).cuda()
+    model = CellposeModel()
+    base = model.eval(x)
+    same = model.eval(x, channels=[0, 0], diameter=30.0, resample=True, augment=False, rescale=None, batch_size=3)
+    assert torch.equal(base[0], same[0]) and torch.equal(base[1][1], same[1][1])  # tiles per forward do not change a bit
+    wide = model.eval(x, bsize=256)
+    assert wide[1][1].shape == base[1][1].shape and not torch.equal(wide[1][1], base[1][1])  # other tiles, other blending
+    for kw in (dict(diameter=17), dict(augment=True), dict(invert=True), dict(rescale=0.5), dict(channels=[2, 1]), dict(resample=False)):
+        with pytest.raises(NotImplementedError):
+            model.eval(x, **kw)
+    with pytest.raises(TypeError):
+        model.eval(x, no_such_keyword=1)
