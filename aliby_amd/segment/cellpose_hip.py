@@ -298,11 +298,15 @@ class CellposeModel:
             x = x[None]
         if isinstance(normalize, dict):
             # cellpose's option dict: the reference passes dict(norm3D=False) on its 3-D branch (dispatch.py:196) = every plane
-            # normalised on its own, which is what a batch of planes gets here.  Anything else in the dict is not built.
-            other = {k: v for k, v in normalize.items() if not (k == "norm3D" and v is False) and not (k == "normalize" and v is True)}
-            if other:
-                raise NotImplementedError(f"normalize options {other} are not built (norm3D=False / normalize=True are)")
-            normalize = True
+            # normalised on its own, which is what a batch of planes gets here (so norm3D is moot for 2-D input).  Keys at the
+            # values that leave cellpose's default normalisation (1st / 99th percentile) unchanged pass; anything else is not built.
+            neutral = {"lowhigh": (None,), "percentile": (None, (1, 99), [1, 99], (1.0, 99.0), [1.0, 99.0]), "sharpen_radius": (0,),
+                       "smooth_radius": (0,), "tile_norm_blocksize": (0,), "invert": (False,)}
+            other_opts = {k: v for k, v in normalize.items() if k not in ("norm3D", "normalize", "tile_norm_smooth3D")
+                          and not (k in neutral and any(v is n or (n is not None and not isinstance(v, bool) and v == n) for n in neutral[k]))}
+            if other_opts:
+                raise NotImplementedError(f"normalize options {other_opts} are not built (percentile normalisation per plane is)")
+            normalize = bool(normalize.get("normalize", True))
         dP = prob = None
         if self.flows_override is None or self.run_network_with_override:
             dP, prob = self.run_network(x, normalize=bool(normalize), bsize=bsize, tile_overlap=tile_overlap, batch_size=batch_size)

@@ -528,3 +528,11 @@ def test_eval_keywords_of_cellpose_are_honoured_or_refused(engine):
             model.eval(x, **kw)
     with pytest.raises(TypeError):
         model.eval(x, no_such_keyword=1)
+    # cellpose's normalize option dict: neutral entries pass, `normalize: False` switches the percentile step off, the rest raises
+    opts = model.eval(x, normalize=dict(norm3D=False, percentile=[1, 99], lowhigh=None, sharpen_radius=0, invert=False))
+    assert torch.equal(opts[1][1], base[1][1])
+    raw = model.eval(x, normalize=dict(normalize=False))
+    assert torch.equal(raw[1][1], model.eval(x, normalize=False)[1][1]) and not torch.equal(raw[1][1], base[1][1])
+    for bad in (dict(percentile=[2, 98]), dict(tile_norm_blocksize=100), dict(lowhigh=[0, 1000]), dict(invert=True)):
+        with pytest.raises(NotImplementedError):
+            model.eval(x, normalize=bad)
