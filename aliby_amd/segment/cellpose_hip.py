@@ -58,7 +58,7 @@ def taper_mask(by, bx, sig=7.5):
 class CellposeModel:
     def __init__(self, gpu=True, device=None, pretrained_model=None, net=None, net_dtype=None, seed=0,
                  flows_override=None, run_network_with_override=False, bsize=224, tile_overlap=0.1, batch_size=288,
-                 use_bfloat16=True, **ignored):
+                 use_bfloat16=True, model_type=None, diam_mean=30.0, nchan=2, fused=True):
         """net_dtype: "bfloat16" (the default) runs the network on the hand-written MFMA kernels (segment/fused_unet.py); "float32" /
         "float16" run the same module through PyTorch's own convolutions (MIOpen: a numerical reference, tens of seconds of kernel
         search at the first batch, several times slower).  `use_bfloat16` is cellpose's spelling of the same switch — the reference
@@ -68,6 +68,13 @@ class CellposeModel:
         574 / 594 / 607 FOV tiles/s end to end at 64 / 128 / 288."""
         if net_dtype is None:
             net_dtype = "bfloat16" if use_bfloat16 else "float32"
+        if model_type is not None:
+            # cellpose resolves a model NAME by downloading its checkpoint; there is no such store here
+            raise ValueError(f"model_type={model_type!r}: built-in models are files cellpose downloads — pass the checkpoint's path "
+                             "as pretrained_model")
+        if int(nchan) != 2:
+            raise NotImplementedError(f"nchan={nchan}: the network built here is CPnet's two-channel residual U-Net")
+        self.diam_mean = float(diam_mean)
         if not gpu or not torch.cuda.is_available():
             raise _lib.AlibyHipError("CellposeModel (HIP) needs a GPU: there is no CPU fallback in this build")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -85,7 +92,7 @@ class CellposeModel:
         torch.backends.cudnn.benchmark = True
         self.net = net.to(self.device).eval()
         self.fused = None
-        if self.net_dtype == torch.bfloat16 and ignored.get("fused", True):
+        if self.net_dtype == torch.bfloat16 and fused:
             from aliby_amd.segment.fused_unet import FusedUNet
 
             self.fused = FusedUNet(self.net, self.eng)  # keeps fp32 master weights, folds BN, bf16 execution
@@ -279,7 +286,7 @@ class CellposeModel:
         if other.get("diameter") not in (None, 0):
             # diameter == the model's diam_mean (30 px for the cyto family, the checkpoint's own value when it carries one) is a
             # rescale factor of one; any other diameter would resize the image before the network, which is not built
-            mean = (getattr(getattr(self, "net", None), "diam", None) or {}).get("diam_mean") or 30.0
+            mean = (getattr(getattr(self, "net", None), "diam", None) or {}).get("diam_mean") or self.diam_mean
             if abs(float(other["diameter"]) - float(mean)) < 1e-6:
                 other = {**other, "diameter": None}
         for k, v in other.items():

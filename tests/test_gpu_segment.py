@@ -528,6 +528,12 @@ def test_eval_keywords_of_cellpose_are_honoured_or_refused(engine):
             model.eval(x, **kw)
     with pytest.raises(TypeError):
         model.eval(x, no_such_keyword=1)
+    with pytest.raises(ValueError):
+        CellposeModel(model_type="cyto3")  # (a NAME is something cellpose downloads: the checkpoint's path goes in pretrained_model)
+    with pytest.raises(NotImplementedError):
+        CellposeModel(nchan=3)
+    with pytest.raises(TypeError):
+        CellposeModel(no_such_option=1)
     # cellpose's normalize option dict: neutral entries pass, `normalize: False` switches the percentile step off, the rest raises
     opts = model.eval(x, normalize=dict(norm3D=False, percentile=[1, 99], lowhigh=None, sharpen_radius=0, invert=False))
     assert torch.equal(opts[1][1], base[1][1])
