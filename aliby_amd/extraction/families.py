@@ -220,6 +220,18 @@ class _NullCtx:
 _NULL_CTX = _NullCtx()
 
 
+# per-feature keywords (cp_measure_kwargs / cp_measure_feature_kwargs of the builder) that the kernels implement
+BUILT_KWARGS = {
+    "intensity": ("edge_measurements",),
+    "texture": ("scale", "gray_levels"),
+    "radial_distribution": ("bin_count", "scaled", "maximum_radius"),
+    "granularity": ("subsample_size", "image_sample_size", "element_size", "granular_spectrum_length", "image_mask", "mask_order"),
+    "manders_fold": ("thr",),
+    "rwc": ("thr",),
+    "costes": ("scale_max",),
+}
+
+
 def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=False):
     """Run every instruction over every object; returns (matrix [n_obj, n_cols] on device, blocks)."""
     register_optional(type(eng))
@@ -231,6 +243,11 @@ def evaluate(eng, labels, table, planes, instructions, cp_measure_kwargs, multi=
         reg = MULTI if (multi and inst[1] == "None") else MONO
         if metric not in reg:
             raise KeyError(metric)
+        # the reference forwards these to the cp_measure function of that name (loaders.py:71-77), where an unknown keyword is an
+        # error; here a keyword the kernels do not implement must not be dropped either
+        unbuilt = sorted(set(kw) - set(BUILT_KWARGS.get(metric, ())))
+        if unbuilt:
+            raise NotImplementedError(f"cp_measure_kwargs[{metric!r}]: {unbuilt} not built (built: {sorted(BUILT_KWARGS.get(metric, ()))})")
         names = reg[metric]["names"](kw)
         blocks.append((col, names))
         specs.append((inst, reg[metric], kw, col, 1 if names is None else len(names)))

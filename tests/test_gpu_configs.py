@@ -295,6 +295,16 @@ def test_coloc_kwargs_are_per_metric(engine):
     b = process_tree_masks(tree, labels, pixels, extract_tree_multi, cp_measure_kwargs={})[1]
     assert any(not np.allclose(x["Correlation_Manders_1"], y["Correlation_Manders_1"]) for x, y in zip(a, b) if "Correlation_Manders_1" in x)
     assert all(np.allclose(x["Correlation_RWC_1"], y["Correlation_RWC_1"]) for x, y in zip(a, b) if "Correlation_RWC_1" in x)
+    # a keyword the kernels do not implement is refused, not dropped (the reference hands it to the cp_measure function, where
+    # an unknown keyword is an error too); keywords of families that the tree does not use are nobody's business
+    from aliby_amd.extraction.extract import extract_tree
+
+    with pytest.raises(NotImplementedError, match="costes"):
+        process_tree_masks(tree, labels, pixels, extract_tree_multi, cp_measure_kwargs={"costes": {"fast_costes": "Accurate"}})
+    mono = {0: {"max": ["intensity"]}, "None": {"None": ["sizeshape"]}}
+    with pytest.raises(NotImplementedError, match="sizeshape"):
+        process_tree_masks(mono, labels, pixels, extract_tree, cp_measure_kwargs={"sizeshape": {"calculate_advanced": False}})
+    process_tree_masks(mono, labels, pixels, extract_tree, cp_measure_kwargs={"texture": {"no_such": 1}})  # (texture is not in the tree)
 
 
 # --------------------------------------------------------------------------------- the position-batched runner
