@@ -260,7 +260,7 @@ def test_fused_unet_matches_module_forward(engine):
     assert torch.equal(ya, yd)
 
 
-@pytest.mark.parametrize("n,h,w", [(4, 256, 256), (3, 128, 128), (2, 176, 208), (5, 64, 96)])
+@pytest.mark.parametrize("n,h,w", [(4, 256, 256), (3, 128, 128), (2, 176, 208), (5, 64, 96), (2, 32, 32), (2, 16, 16), (7, 24, 40)])
 def test_fused_unet_at_other_tile_sizes(engine, n, h, w):
     """The network at tile sizes other than cellpose 3's 224 x 224 — `eval(bsize=256)` (cellpose 4's default), small images
     (one tile of the image's own padded size, a multiple of 16), odd batch sizes: the packed / tall / paired launch forms are
