@@ -81,6 +81,9 @@ class Tiler:
         # 8-bit sources (uint8 / bool) are stored as uint16 on the device; the mark travels with the step's pixel arrays so that the
         # texture kernel takes their grey level unchanged, as skimage.util.img_as_ubyte does for uint8 (engine.to_device_planes)
         self.eight_bit = str(getattr(pixels, "dtype", "")) in ("uint8", "bool", "torch.uint8", "torch.bool")
+        # float stacks (already normalised data): float32 on the device, monotile positions only; the runner keeps such positions
+        # on its host-typed tile path, like the 8-bit ones
+        self.float_source = str(getattr(pixels, "dtype", "")).replace("torch.", "") in ("float16", "float32", "float64")
         self.meta = meta
         self.channels = list(range(pixels.shape[-4]))
         if self.tile_size is not None:
@@ -225,6 +228,8 @@ class Tiler:
         if isinstance(block, torch.Tensor):
             if block.dtype in (torch.uint8, torch.bool):
                 block = block.to(torch.int32).to(torch.uint16)
+            elif block.dtype.is_floating_point:
+                block = block.to(torch.float32)
             if target is not None and tuple(target.shape) == tuple(block.shape) and block.dtype == target.dtype:
                 target.copy_(block, non_blocking=True)
                 return target
@@ -232,14 +237,16 @@ class Tiler:
         block = np.ascontiguousarray(block)
         if block.dtype in (np.uint8, np.bool_):
             block = block.astype(np.uint16)
-        if block.dtype != np.uint16:
+        elif block.dtype.kind == "f":
+            block = block.astype(np.float32)
+        if block.dtype not in (np.uint16, np.float32):
             raise NotImplementedError(
-                f"stager handles uint16 stacks (the reference's fixtures, SURVEY §3.3); got {block.dtype}"
+                f"stager handles uint16, 8-bit and float stacks (the reference's fixtures are uint16, SURVEY §3.3); got {block.dtype}"
             )
         src = torch.from_numpy(block)
         # page-locked host memory goes up asynchronously on the current stream at PCIe rate (pageable memory is staged by the
         # runtime at a quarter of it); torch's host allocator keeps a pinned block alive until the copy has run
-        if target is not None and tuple(target.shape) == tuple(src.shape):
+        if target is not None and tuple(target.shape) == tuple(src.shape) and target.dtype == src.dtype:
             target.copy_(src, non_blocking=src.is_pinned())
             return target
         return src.cuda(non_blocking=src.is_pinned())
@@ -306,6 +313,9 @@ class Tiler:
             # monotile window = the whole frame: the stack itself is the tile block, no copy
             self._crop_cache = (key, stack[None], flags[:F])
             return stack[None], flags[:F]
+        if stack.dtype != torch.uint16:
+            raise NotImplementedError(f"tiles cropped out of {stack.dtype} stacks are not built (the stager crops uint16; a float "
+                                      "stack goes through as ONE tile: tile_size=None)")
         out = torch.empty((F, C, Z, h, w), dtype=torch.uint16, device=stack.device)
         if F:
             _lib.check(
@@ -327,6 +337,8 @@ class Tiler:
             return host
         if self.eight_bit:
             host = host.astype(np.uint8)  # (the dtype the reference's tiler hands on)
+        elif self.float_source and str(getattr(self.pixels, "dtype", "")).replace("torch.", "") == "float64":
+            host = host.astype(np.float64)
         return devcache.attach(host, dev, kind="pixels", eight_bit=self.eight_bit)
 
     def get_tp_channel(self, tp: int, c: int, drift: bool = True) -> np.ndarray:

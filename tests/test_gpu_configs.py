@@ -430,6 +430,47 @@ def test_eight_bit_sources_through_the_pipeline(tmp_path, engine):
             assert np.nanmax(ent) > 1.0  # (value >> 8 would have left one grey level: no entropy at all)
 
 
+def test_float_sources_through_the_pipeline(tmp_path, engine):
+    """float stacks (data normalised upstream): float32 on the device, one tile per position; single calls and the batched
+    runner agree, the numbers are those of the float pixels (checked on the mean intensity against NumPy)."""
+    from aliby_amd.parallel import run_positions
+    from aliby_amd.pipe import run_pipeline_and_post
+    from aliby_amd.pipe_builder import build_pipeline_steps
+
+    fovs = [synth.make_fov(2, 150 + i, shape=(224, 256), n_channels=2, n_target=8) for i in range(2)]
+    pf = [(f["pixels"].astype(np.float32) / np.float32(30000.0)).clip(0, 1) for f in fovs]
+    override = _keyed_override([dict(nuclei=f["nuclei"], pixels=p) for f, p in zip(fovs, pf)])
+
+    def pipelines(dtype):
+        out = []
+        for p32 in pf:
+            p = build_pipeline_steps(channels_to_segment={"nuclei": 0}, channels_to_extract=[0, 1],
+                                     features_to_extract=("sizeshape", "intensity", "texture"))
+            p["steps"]["tile"]["image_kwargs"] = {"source": p32.astype(dtype)[None]}
+            p["steps"]["segment_nuclei"]["segmenter_kwargs"]["setup_params"] = dict(flows_override=override)
+            out.append(p)
+        return out
+
+    names = ["F0", "F1"]
+    single = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=tmp_path / "s")[0] for p, nm in zip(pipelines(np.float32), names)]
+    batched = [r[0] for r in run_positions(pipelines(np.float32), names, tmp_path / "b", batch_size=2)]
+    double = [run_pipeline_and_post(pipeline=p, pipeline_name=nm, output_path=tmp_path / "d")[0] for p, nm in zip(pipelines(np.float64), names)]
+    for i, nm in enumerate(names):
+        assert single[i].num_rows == batched[i].num_rows == double[i].num_rows == int(fovs[i]["nuclei"].max())
+        for c in single[i].column_names:
+            a, b, d = (t[i][c].to_numpy(zero_copy_only=False) for t in (single, batched, double))
+            if a.dtype.kind != "f":
+                assert np.array_equal(a, b) and np.array_equal(a, d), c
+            else:
+                assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), c
+                assert np.allclose(a, d, rtol=1e-9, atol=1e-12, equal_nan=True), c  # (float64 stacks are float32 on the device)
+        with np.load(tmp_path / "s" / "steps" / nm / "segment_nuclei" / "0000.npz") as z:
+            labels = z["arr_0"]
+        want = np.array([pf[i][1, 0][labels == k].astype(np.float64).mean() for k in range(1, int(labels.max()) + 1)])
+        got = single[i]["1/max/intensity/Intensity_MeanIntensity"].to_numpy(zero_copy_only=False)
+        assert np.allclose(got, want, rtol=1e-6)
+
+
 def _same(a, b):
     if isinstance(a, dict):
         return isinstance(b, dict) and sorted(a) == sorted(b) and all(_same(a[k], b[k]) for k in a)
