@@ -278,8 +278,14 @@ def test_fused_unet_at_other_tile_sizes(engine, n, h, w):
             m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
     x = torch.randn(n, 2, h, w, generator=g).cuda().contiguous()
-    with torch.no_grad():
-        y_ref, s_ref = net(x)
+    # (the fp32 module is the yardstick, not a benchmark: without this, MIOpen searches its kernels anew for every shape — 20 s each —
+    # once an earlier test's CellposeModel has switched the benchmark mode on)
+    bench_mode, torch.backends.cudnn.benchmark = torch.backends.cudnn.benchmark, False
+    try:
+        with torch.no_grad():
+            y_ref, s_ref = net(x)
+    finally:
+        torch.backends.cudnn.benchmark = bench_mode
     y, s = FusedUNet(net, engine)(x)
     assert y.shape == y_ref.shape == (n, 3, h, w)
     err = float((y - y_ref).norm() / y_ref.norm())
