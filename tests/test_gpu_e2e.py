@@ -255,3 +255,25 @@ def test_cell_painting_example_script_runs_from_tiffs(tmp_path, engine, monkeypa
     out = capsys.readouterr().out
     assert "6 parquet files" in out and "every synthetic nucleus is one row" in out
     assert len(list((tmp_path / "out" / "profiles").glob("*.parquet"))) == 6
+
+
+def test_timelapse_example_script_runs_from_a_zarr_store(tmp_path, engine, monkeypatch, capsys):
+    """examples/yeast_timelapse_zarr.py: zarr store -> DatasetZarr positions -> trap tiles + drift -> per-tile segmentation (an
+    intensity-gradient flow field through `flows_override`) -> stitch tracker -> features, the data side of the reference's
+    examples/03 with this build's segmenter in BABY's place."""
+    import runpy
+    import sys
+    from pathlib import Path
+
+    script = Path(__file__).resolve().parents[1] / "examples" / "yeast_timelapse_zarr.py"
+    monkeypatch.setattr(sys, "argv", [str(script), "--positions", "2", "--tps", "3", "--out", str(tmp_path / "out")])
+    runpy.run_path(str(script), run_name="__main__")
+    out = capsys.readouterr().out
+    assert "pos000:" in out and "pos001:" in out and "9 trap tiles" in out
+    files = sorted((tmp_path / "out" / "profiles").glob("*.parquet"))
+    assert [f.stem for f in files] == ["pos000", "pos001"]
+    import pyarrow.parquet as pq
+
+    t = pq.read_table(files[0]).to_pandas()
+    assert sorted(t["metadata_tp"].unique().tolist()) == [0, 1, 2] and len(t) > 0
+
