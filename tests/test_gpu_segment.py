@@ -456,6 +456,24 @@ def test_dynamics_do_not_depend_on_what_the_workspace_held(engine):
             assert np.array_equal(got.cpu().numpy(), ref[sl]), (fill, sl)
 
 
+def test_dynamics_direct_gather_form_has_the_same_labels(engine, monkeypatch):
+    """ALIBY_DYN_DIRECT=1: the flow following gathers from (dP, cellprob) themselves instead of from a normalised copy of the flow
+    field (less HBM traffic, a little slower, not the default): end points and labels bit for bit those of the default form."""
+    import torch
+    from aliby_amd.segment.dynamics import masks_from_flows
+
+    tiles = [_flows((256, 288), 26, fov, "cells") for fov in (0, 1, 2)]
+    dP = torch.from_numpy(np.stack([t[1] for t in tiles])).cuda()
+    prob = torch.from_numpy(np.stack([t[2] for t in tiles])).cuda()
+    la, na, pa = masks_from_flows(engine, dP, prob, return_endpoints=True)
+    la, pa = la.clone(), pa.clone()
+    monkeypatch.setenv("ALIBY_DYN_DIRECT", "1")
+    lb, nb, pb = masks_from_flows(engine, dP, prob, return_endpoints=True)
+    assert torch.equal(la, lb) and np.array_equal(na, nb)
+    fg = (prob > 0)[:, None].expand_as(pa)
+    assert torch.equal(pa[fg], pb[fg])
+
+
 @pytest.mark.gpu
 def test_dynamics_do_not_depend_on_the_order_of_the_foreground_list(engine, monkeypatch):
     """The foreground pixels are compacted in 4096-pixel chunks whose order in the list is the order their workgroups reserved
