@@ -346,15 +346,19 @@ def _join_on_metadata(left: pa.Table, right: pa.Table, strict: bool = False) -> 
     right table's other columns, without building an Acero plan for a thousand-column table (tens of ms per position).
     Anything else goes through pyarrow's join."""
     keys = [f"metadata_{k}" for k in _META_KEYS]
-    if left.num_rows == right.num_rows and all(k in left.column_names and k in right.column_names for k in keys) and all(
-            left[k].equals(right[k]) for k in keys) and not (set(left.column_names) & set(right.column_names)) - set(keys):
-        out = left
-        names = list(left.column_names)
-        arrays = list(left.columns)
-        for name in right.column_names:
-            if name not in keys:
+    # (column lists taken once: `table[name]` and `table.column_names` cost a pass over a thousand fields each)
+    lnames, rnames = left.column_names, right.column_names
+    lcols, rcols = left.columns, right.columns
+    lpos, rpos = {n: i for i, n in enumerate(lnames)}, {n: i for i, n in enumerate(rnames)}
+    keyset = set(keys)
+    if left.num_rows == right.num_rows and all(k in lpos and k in rpos for k in keys) and all(
+            lcols[lpos[k]].equals(rcols[rpos[k]]) for k in keys) and not (set(lnames) & set(rnames)) - keyset:
+        names = list(lnames)
+        arrays = list(lcols)
+        for name, col in zip(rnames, rcols):
+            if name not in keyset:
                 names.append(name)
-                arrays.append(right[name])
+                arrays.append(col)
         return pa.Table.from_arrays(arrays, names=names)
     if strict:  # the caller relies on the row order of the left table: no plan-ordered join
         return None
