@@ -333,9 +333,10 @@ class BatchRunner:
             if name not in pos.state["fn"]:
                 pos.state["fn"][name] = self.shared.get(name, pos.pipeline["steps"][name], pos.state["fn"])
             tilers.append(pos.state["fn"][name])
+        # (8-bit sources: the mark that texture needs travels with the host arrays' registrations, tile/tiler.py; float sources keep
+        # their own dtype there too — both stay on the host-typed path)
         on_device = all(hasattr(t, "run_tp_device") and not getattr(t, "eight_bit", False) and not getattr(t, "float_source", False)
-                        for t in tilers)  # (8-bit sources: the
-        # mark that texture needs travels with the host arrays' registrations, tile/tiler.py)
+                        for t in tilers)
         if any(name in (pos.pipeline.get("save") or []) for pos in batch) or not on_device:
             return [pipe_core.run_step(t, tp=tp) for t in tilers]  # host path: the reference's own container types
         # monotile positions of one shape: every stack is uploaded into its slice of ONE [B,C,Z,Y,X] block, so the batch the
