@@ -138,7 +138,17 @@ __global__ __launch_bounds__(256) void k_cell(CellArgs a) {
         const long long v = dr * dr + dc * dc;
         if (v < best) best = v;
       }
-      if (best != LLONG_MAX) ctsum += sqrt((double)best);
+      if (best != LLONG_MAX) {
+        ctsum += sqrt((double)best);
+      } else {
+        // every pixel of the object is a top pixel (an object one or two pixels thick: all at the same distance from the edge).
+        // The reference then asks scipy for distance_transform_edt(dn == 0) of a frame WITHOUT background (cell.py:223); scipy
+        // answers with the distance to the virtual point one row above the first column of the (padded) frame,
+        // sqrt((row + 1)^2 + col^2).  Not a geometric quantity, but it is what the reference's volume / eccentricity /
+        // min_maj_approximation return for such objects, so it is what is returned here (oracle/cell_metrics.py calls scipy).
+        const double yp = (double)(o.y0 + tr - 1) + 1.0, xp = (double)(o.x0 + tc - 1) + 1.0;  // padded full-frame coordinates
+        ctsum += sqrt((yp + 1.0) * (yp + 1.0) + xp * xp);
+      }
     }
     const double CTS = block_sum_f64(ctsum, red_d);
     const double area = (double)o.area;

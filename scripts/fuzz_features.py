@@ -1,0 +1,41 @@
+"""Randomised differential run of every feature family against the oracle on irregular label images: thresholded smoothed noise
+(concave blobs, holes, one-pixel specks, objects on the frame border, very different sizes in one frame).
+usage: python scripts/fuzz_features.py [first_seed=0] [n=12]     (GPU box; about 10 s per seed, most of it the oracle)"""
+import sys
+import time
+
+import numpy as np
+from scipy import ndimage as ndi
+
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from test_gpu_edge_cases import _run_both  # noqa: E402
+
+first, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 12)
+MONO = ["intensity", "feret", "zernike", "radial_zernikes", "texture", "radial_distribution", "median", "max2p5pc", "mean", "std"]
+for seed in range(first, first + n):
+    rng = np.random.default_rng(1000 + seed)
+    Y, X = int(rng.integers(96, 260)), int(rng.integers(96, 300))
+    sigma = float(rng.uniform(1.5, 5.0))
+    field = ndi.gaussian_filter(rng.standard_normal((Y, X)), sigma)
+    lab, k = ndi.label(field > np.quantile(field, rng.uniform(0.55, 0.85)))
+    # a few specks and a thin line, then sequential labels in raster order of first appearance (as a segmenter hands them on)
+    for _ in range(3):
+        y, x = int(rng.integers(0, Y)), int(rng.integers(0, X))
+        if lab[y, x] == 0 and not lab[max(0, y - 1) : y + 2, max(0, x - 1) : x + 2].any():
+            k += 1
+            lab[y, x] = k
+    if k > 60:  # (the oracle loops over objects x families: keep a seed within seconds)
+        keep = rng.choice(np.arange(1, k + 1), 60, replace=False)
+        lab = np.where(np.isin(lab, keep), lab, 0)
+    _, inv = np.unique(lab, return_inverse=True)
+    lab = inv.reshape(Y, X).astype(np.uint16)
+    C, Z = 2, int(rng.integers(1, 3))
+    px = rng.integers(0, 4000, size=(1, C, Z, Y, X)).astype(np.uint16)
+    px += (ndi.gaussian_filter(rng.standard_normal((Y, X)), 3.0) * 6000 + 8000).clip(0, 40000).astype(np.uint16)[None, None, None]
+    t0 = time.perf_counter()
+    tree = {"None": {"None": ["sizeshape", "area", "volume"]}, 0: {"max": MONO}, 1: {"max": ["intensity", "texture"]}}
+    _run_both(tree, [lab], px)
+    _run_both({(0, 1): {"None": {"max": ["pearson", "costes", "manders_fold", "rwc"]}}}, [lab], px, multi=True)
+    print(f"seed {seed}: {Y}x{X}, {int(lab.max())} objects, areas {np.bincount(lab.ravel())[1:].min()}..{np.bincount(lab.ravel())[1:].max()}, "
+          f"sigma {sigma:.1f}: ok ({time.perf_counter() - t0:.1f} s)", flush=True)
