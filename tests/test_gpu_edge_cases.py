@@ -20,7 +20,14 @@ def _close(a, b, key, rtol=1e-4):
         a, b = np.atleast_1d(a), np.atleast_1d(b)
         flip = (np.isclose(np.abs(a), 45.0) & np.isclose(np.abs(b), 45.0)) | (np.isclose(np.abs(a), 90.0) & np.isclose(np.abs(b), 90.0))
         a, b = a[~flip], b[~flip]
-    assert np.allclose(a, b, rtol=rtol, atol=1e-8, equal_nan=True), (key, a.ravel()[:4], b.ravel()[:4])
+    if "ZernikePhase" in key:  # an angle: -pi and +pi are one phase (a real negative moment, either side of atan2's branch cut)
+        a, b = np.atleast_1d(a), np.atleast_1d(b)
+        wrap = np.isclose(np.abs(a), np.pi) & np.isclose(np.abs(b), np.pi)
+        a, b = a[~wrap], b[~wrap]
+    # InfoMeas2 = sqrt(1 - exp(-2 (HXY2 - HXY))): where the two entropies are equal (independent grey levels) the argument is a
+    # few ulps of 1 and the square root turns 4e-16 into 3e-8 — or into exactly 0 when the difference rounds to zero
+    atol = 1e-6 if "InfoMeas2" in key else 1e-8
+    assert np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True), (key, a.ravel()[:4], b.ravel()[:4])
 
 
 def _run_both(tree, masks, pixels, multi=False, kw=None):
@@ -35,6 +42,10 @@ def _run_both(tree, masks, pixels, multi=False, kw=None):
         if isinstance(b, dict):
             assert set(a) == set(b)
             for k in b:
+                if "ZernikePhase" in k:  # the phase of a vanishing moment (a one-pixel object, a symmetric one) is rounding noise
+                    mag = k.replace("ZernikePhase", "ZernikeMagnitude")
+                    if mag in b and np.all(np.abs(np.asarray(b[mag], float)) < 1e-9) and np.all(np.abs(np.asarray(a[mag], float)) < 1e-9):
+                        continue
                 _close(a[k], b[k], f"{inst[i][1]}/{k}")
         else:
             _close(a, float(b), str(inst[i][1]))
