@@ -1,7 +1,7 @@
 """Randomised differential run of the Cellpose dynamics (flows -> label image) against the oracle: flow fields of irregular
 label images (thresholded smoothed noise: concave blobs, holes, specks, touching the border) with noise on the flows, perturbed
 cell probabilities, random thresholds; several frames per call.  Bit-exact labels expected.
-usage: python scripts/fuzz_dynamics.py [first_seed=0] [n=20]     (GPU box)"""
+usage: python tests/fuzz/fuzz_dynamics.py [first_seed=0] [n=20]     (GPU box)"""
 import sys
 import time
 

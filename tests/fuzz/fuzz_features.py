@@ -1,6 +1,6 @@
 """Randomised differential run of every feature family against the oracle on irregular label images: thresholded smoothed noise
 (concave blobs, holes, one-pixel specks, objects on the frame border, very different sizes in one frame).
-usage: python scripts/fuzz_features.py [first_seed=0] [n=12] [extras]     (GPU box; well under a second per seed)"""
+usage: python tests/fuzz/fuzz_features.py [first_seed=0] [n=12] [extras]     (GPU box; well under a second per seed)"""
 import sys
 import time
 

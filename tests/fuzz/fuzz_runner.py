@@ -1,7 +1,7 @@
 """Randomised differential run of the position-batched runner against one run_pipeline_and_post per position: random numbers of
 positions, frame shapes, channels, Z, feature selections, batch sizes, empty positions.  Integer columns and label images exact,
 float columns to 1e-9 of the column's scale (a batch sizes its workgroups for its largest object: INTEGRATION.md 2.1).
-usage: python scripts/fuzz_runner.py [first_seed=0] [n=20]     (GPU box)"""
+usage: python tests/fuzz/fuzz_runner.py [first_seed=0] [n=20]     (GPU box)"""
 import shutil
 import sys
 import tempfile

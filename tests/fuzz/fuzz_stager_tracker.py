@@ -1,7 +1,7 @@
 """Randomised differential runs of the smaller kernels against the oracle: crop + median pad (random windows leaving the frame on
 any side), the IoU stitch tracker over random label sequences (objects appearing, vanishing, splitting, label gaps), percentile
 normalisation (narrow ranges, ties, constant images) and the object table (random labels with gaps).
-usage: python scripts/fuzz_stager_tracker.py [first_seed=0] [n=50]     (GPU box)"""
+usage: python tests/fuzz/fuzz_stager_tracker.py [first_seed=0] [n=50]     (GPU box)"""
 import sys
 
 import numpy as np

@@ -1,6 +1,6 @@
 """Randomised differential runs against the oracle: network tiling + blending at random frame sizes / tile sizes / overlaps
 (float32 bit-exact), and the drift estimate (phase cross-correlation) on randomly shifted, noisy frames.
-usage: python scripts/fuzz_tiles_drift.py [first_seed=0] [n=40]     (GPU box)"""
+usage: python tests/fuzz/fuzz_tiles_drift.py [first_seed=0] [n=40]     (GPU box)"""
 import sys
 
 import numpy as np

@@ -97,7 +97,7 @@ def test_thin_objects_where_every_pixel_is_the_cone_top(engine):
     """cell.py's min_maj_approximation (cell.py:207-229) on an object one or two pixels thick — every pixel at the same distance
     from the edge — ends in `distance_transform_edt` of a frame without background, for which scipy returns the distance to a
     virtual point above the frame's first column.  volume / eccentricity of such objects carry that number (it depends on where
-    the object lies in the frame); the kernel returns the same.  Found by scripts/fuzz_features.py (the kernel returned 0)."""
+    the object lies in the frame); the kernel returns the same.  Found by tests/fuzz/fuzz_features.py (the kernel returned 0)."""
     lab = np.zeros((96, 128), np.uint16)
     lab[5, 7] = 1                  # one pixel
     lab[20:22, 30:32] = 2          # 2 x 2
