@@ -56,7 +56,12 @@ class StitchTracker:
         pairs = []
         if len(masks) and all(len(pair) == 1 for pair in masks):
             # first timepoint: nothing to stitch against, every object keeps its own label
-            cur = torch.stack([self._dev(pair[0]) for pair in masks]).contiguous()
+            first = [self._dev(pair[0]) for pair in masks]
+            if any(a.ndim != 2 for a in first):
+                # (a monotile segmenter without per_tile=True hands on ONE [Y,X] image, which the engine's regrouping takes for Y
+                # tiles of one row each: pipe_core.py:195-200 — the tracker wants the per-tile list)
+                raise AssertionError("Masks are in wrong dimensions")
+            cur = torch.stack(first).contiguous()
             tc = self.eng.object_table(cur)
             out = TrackResult()
             for k in range(len(masks)):
