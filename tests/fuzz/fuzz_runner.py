@@ -83,7 +83,7 @@ def timelapse(seed):
 if TIMELAPSE:
     for seed in range(first, first + n):
         timelapse(seed)
-    sys.exit(0)
+    n = 0  # (nothing left for the single-time-point loop below)
 FEATS = ("sizeshape", "intensity", "texture", "radial_distribution", "zernike", "feret", "radial_zernikes")
 for seed in range(first, first + n):
     rng = np.random.default_rng(11000 + seed)
