@@ -22,6 +22,7 @@ SCRIPTS = Path(__file__).resolve().parent / "fuzz"
     ("fuzz_tiles_drift.py", ["0", "8"]),
     ("fuzz_runner.py", ["0", "6"]),
     ("fuzz_runner.py", ["0", "5", "timelapse"]),
+    ("fuzz_overlap.py", ["0", "20"]),
 ])
 def test_randomised_differential_runs(engine, monkeypatch, capsys, script, args):
     monkeypatch.setattr(sys, "argv", [str(SCRIPTS / script), *args])
