@@ -323,6 +323,8 @@ class FeatureEngine:
         offsets = np.zeros(F + 1, np.int32)
         np.cumsum(np.asarray(counts, np.int32), out=offsets[1:])
         out = self.new_output(int(offsets[-1]), 12)
+        if int(offsets[-1]) == 0:
+            return out  # stacks without any object: an empty block (found by tests/fuzz/fuzz_volume.py — the C entry refuses a NULL output)
         with self.timed("intensity3d"):
             _lib.check(self.lib.aliby_features_intensity3d(self.ctx.handle, _ptr(volume.contiguous()), _ptr(pixels.contiguous()), F, pixels.shape[1], Z, Y,
                                                            X, int(channel), _ptr(offsets), _ptr(out), out.stride(0) if out.numel() else 12, 0,

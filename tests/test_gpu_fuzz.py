@@ -23,6 +23,7 @@ SCRIPTS = Path(__file__).resolve().parent / "fuzz"
     ("fuzz_runner.py", ["0", "6"]),
     ("fuzz_runner.py", ["0", "5", "timelapse"]),
     ("fuzz_overlap.py", ["0", "20"]),
+    ("fuzz_volume.py", ["540", "30"]),  # (seed 553: a stack without any object)
 ])
 def test_randomised_differential_runs(engine, monkeypatch, capsys, script, args):
     monkeypatch.setattr(sys, "argv", [str(SCRIPTS / script), *args])
