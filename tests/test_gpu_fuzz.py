@@ -24,6 +24,7 @@ SCRIPTS = Path(__file__).resolve().parent / "fuzz"
     ("fuzz_runner.py", ["0", "5", "timelapse"]),
     ("fuzz_overlap.py", ["0", "20"]),
     ("fuzz_volume.py", ["540", "30"]),  # (seed 553: a stack without any object)
+    ("fuzz_traps.py", ["108", "8"]),  # (seed 114: no usable template — both sides raise "No valid tiles found.")
 ])
 def test_randomised_differential_runs(engine, monkeypatch, capsys, script, args):
     monkeypatch.setattr(sys, "argv", [str(SCRIPTS / script), *args])
