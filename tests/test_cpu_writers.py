@@ -173,3 +173,19 @@ def test_native_writers_fail_loudly_on_a_path_they_cannot_open(tmp_path):
     assert pq.read_table(tmp_path / "ok.parquet")["a"].to_pylist() == [1.0, 2.0, 3.0]
     assert W.write_npz_native(tmp_path / "ok.npz", {"arr_0": np.arange(4)})
     assert np.load(tmp_path / "ok.npz")["arr_0"].tolist() == [0, 1, 2, 3]
+
+
+def test_randomised_tables_and_label_arrays_read_back(monkeypatch, capsys):
+    """tests/fuzz/fuzz_writers.py (3300 seeds by hand): random profile-shaped tables — NaN / inf / extreme floats, int64, uint16,
+    non-ASCII strings and column names, empty tables — and random label arrays through the native encoders, read back with
+    pyarrow / numpy."""
+    import runpy
+    import sys
+    from pathlib import Path
+
+    script = Path(__file__).resolve().parent / "fuzz" / "fuzz_writers.py"
+    monkeypatch.setattr(sys, "argv", [str(script), "0", "40"])
+    monkeypatch.chdir(script.parents[2])
+    runpy.run_path(str(script), run_name="__main__")
+    assert "40 seeds ok" in capsys.readouterr().out
+
