@@ -427,3 +427,17 @@ def test_tiff_hostile_fields_are_refused_not_fatal(tmp_path, name, tag, value, d
     assert run.returncode == 0, (run.returncode, run.stderr[-800:])
     rc0, rc1 = (int(x) for x in run.stdout.split("RC")[1].split())
     assert rc0 != 0 and rc1 != 0  # both entry points refuse the page
+
+
+def test_randomised_tiff_round_trips(monkeypatch, capsys):
+    """tests/fuzz/fuzz_tiff.py (5400 seeds by hand): planes of random size (down to 1 x 1) and dtype, uncompressed or Deflate, random
+    strip heights, written by the minimal baseline writer and read back through ImageMultiTiff."""
+    import runpy
+    import sys
+
+    script = Path(__file__).resolve().parent / "fuzz" / "fuzz_tiff.py"
+    monkeypatch.setattr(sys, "argv", [str(script), "0", "60"])
+    monkeypatch.chdir(script.parents[2])
+    runpy.run_path(str(script), run_name="__main__")
+    assert "60 seeds ok" in capsys.readouterr().out
+
